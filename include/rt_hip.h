@@ -1,0 +1,198 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) trace-loop library.
+ *
+ * The library replaces exactly one call of the reference ray tracer:
+ *
+ *     void render(camera* c, world* w)            RayTracer/RayTracer.c:1574
+ *
+ * i.e. for every pixel: ray_for_pixel (RayTracer.c:1535) -> color_at(w, r, 5)
+ * (RayTracer.c:1426) -> write_pixel (RayTracer.c:257), followed by the 8-bit
+ * quantisation of color_convert (RayTracer.c:1322) that write_canvas_to_file
+ * (RayTracer.c:1333) applies when it emits the image.
+ *
+ * The caller keeps building its scene with its own constructors, flattens the
+ * `world` linked list (RayTracer.c:92) into the plain arrays of `rt_scene`
+ * below (rt_scene.h has a C helper that does it with the reference's
+ * arithmetic), uploads it once, and calls rt_hip_render() wherever it called
+ * render().  Plain C types only; the caller owns every host buffer, the
+ * library owns every device buffer except the ones handed to the *_device
+ * entry points.
+ *
+ * All entry points return RT_OK (0) or a negative rt_status; none aborts.
+ * The library keeps one context per process (the reference itself is a
+ * single global `canvas`/`contents`, RayTracer.c:102,255) and is not
+ * re-entrant: one process drives one GPU.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,     /* NULL / out-of-range argument                      */
+  RT_ERR_NO_DEVICE = -2,   /* no HIP device, or ordinal out of range             */
+  RT_ERR_HIP = -3,         /* a HIP runtime call failed (see rt_hip_last_error)  */
+  RT_ERR_UNSUPPORTED = -4, /* scene uses something outside the path (non-affine
+                              transform, pattern, transparency, ...)            */
+  RT_ERR_NOT_READY = -5,   /* init / upload_scene has not been called            */
+  RT_ERR_TOO_LARGE = -6    /* scene or image exceeds a documented limit          */
+} rt_status;
+
+/* Subset of `material` (RayTracer.c:57) that lighting() (RayTracer.c:1273) and
+ * reflected_color() (RayTracer.c:1443) read when has_pattern == false and
+ * transparency == 0. */
+typedef struct rt_material {
+  double color[3];
+  double ambient;
+  double diffuse;
+  double specular;
+  double shininess;
+  double reflective;
+} rt_material;
+
+/* `camera` (RayTracer.c:96) with the loop-invariant inverse(view_transform)
+ * that ray_for_pixel recomputes twice per pixel (RayTracer.c:1553,1562)
+ * hoisted to the host.  Row-major 4x4. */
+typedef struct rt_camera {
+  int32_t hsize;
+  int32_t vsize;
+  double pixel_size;
+  double half_width;
+  double half_height;
+  double inv_view[16];
+} rt_camera;
+
+/* First (and only used) `point_light` of the world, RayTracer.c:59,1411,1489. */
+typedef struct rt_light {
+  double position[3];
+  double intensity[3];
+} rt_light;
+
+/* One node of the host-built bounding volume hierarchy over the triangles.
+ * Inner node (right > 0): children are nodes `left` and `right`.
+ * Leaf (right < 0): holds -right triangles, bvh_tri[left .. left - right).
+ * Node 0 is the root.  Boxes are padded outwards so that a box test can only
+ * produce false positives, never drop a triangle the exhaustive walk of
+ * intersect_world (RayTracer.c:1043) would have hit. */
+typedef struct rt_bvh_node {
+  float lo[3];
+  int32_t left;   /* inner: left child index;  leaf: first slot in bvh_tri */
+  float hi[3];
+  int32_t right;  /* inner: right child index (> 0);  leaf: -(count)        */
+} rt_bvh_node;
+
+/* Flattened `world` (RayTracer.c:92).  Every primitive keeps its position in
+ * the world's linked list (`*_order`): when two primitives are hit at exactly
+ * the same t the reference's stable sort + hit() (RayTracer.c:139-157) keeps
+ * the one that comes first in the list, and so does the library. */
+typedef struct rt_scene {
+  rt_camera camera;
+  rt_light light;
+
+  int32_t n_materials;
+  const rt_material* materials;
+
+  /* spheres: unit sphere under `transform`; the library needs only
+   * inverse(transform) (row-major, bottom row must be exactly 0 0 0 1). */
+  int32_t n_spheres;
+  const double* sph_inv;        /* [n_spheres][16]                               */
+  const int32_t* sph_material;  /* [n_spheres] index into materials             */
+  const int32_t* sph_order;     /* [n_spheres] position in the world list       */
+
+  /* triangles, structure of arrays: 12 rows of n_tris doubles, row r at
+   * tri_soa + r * n_tris, rows = p1.x p1.y p1.z e1.x e1.y e1.z e2.x e2.y e2.z
+   * n.x n.y n.z with e1 = p2 - p1, e2 = p3 - p1, n = normalize(e2 x e1)
+   * exactly as create_triangle computes them (RayTracer.c:1004-1006). */
+  int32_t n_tris;
+  const double* tri_soa;
+  const int32_t* tri_material;  /* [n_tris]                                      */
+  const int32_t* tri_order;     /* [n_tris]                                      */
+
+  /* optional BVH over the triangles (NULL / 0 = none; brute force is used). */
+  int32_t n_bvh_nodes;
+  const rt_bvh_node* bvh_nodes;
+  const int32_t* bvh_tri;       /* [n_tris] triangle indices in leaf order      */
+} rt_scene;
+
+enum {
+  RT_ACCEL_AUTO = 0,   /* BVH when the scene has one and enough triangles      */
+  RT_ACCEL_BRUTE = 1,  /* every ray tests every primitive (the reference's way) */
+  RT_ACCEL_BVH = 2
+};
+
+/* One render() call.  The image is camera.hsize x camera.vsize.  With
+ * n_ranks > 1 the rows are dealt to ranks in bands of band_rows rows,
+ * round-robin (band b belongs to rank b % n_ranks) and the call renders only
+ * this rank's rows, packed in increasing y. */
+typedef struct rt_render_params {
+  int32_t max_depth;    /* RECURSION_DEPTH, RayTracer.c:40 (the reference: 5)   */
+  int32_t spp_grid;     /* g: g x g sub-pixel samples per pixel; 1 = reference  */
+  int32_t accel;        /* RT_ACCEL_*                                            */
+  int32_t count_rays;   /* != 0: fill rt_stats ray counters (slower kernel)     */
+  int32_t band_rows;    /* rows per band (>= 1); ignored when n_ranks == 1      */
+  int32_t n_ranks;      /* >= 1                                                  */
+  int32_t rank;         /* 0 .. n_ranks-1                                        */
+  int32_t reserved;
+} rt_render_params;
+
+typedef struct rt_stats {
+  uint64_t rays_primary;    /* ray_for_pixel calls                               */
+  uint64_t rays_shadow;     /* is_shadowed calls (one per shaded hit)            */
+  uint64_t rays_secondary;  /* reflected rays spawned                            */
+  uint64_t prim_tests;      /* ray-primitive tests executed                      */
+  uint64_t node_tests;      /* ray-box tests executed (BVH only)                 */
+  double kernel_ms;         /* hipEvent time of the trace kernel, this call      */
+  int32_t rows_rendered;    /* rows this rank produced                           */
+  int32_t accel_used;       /* RT_ACCEL_BRUTE or RT_ACCEL_BVH                    */
+} rt_stats;
+
+/* Bind the process to HIP device `device` and create the stream and events.
+ * Replaces nothing in the reference (it has no device); call once. */
+int rt_hip_init(int device);
+
+/* Copy the flattened world + camera + light to the device.  Replaces the
+ * pointer arguments of render(camera*, world*), RayTracer.c:1574: the scene
+ * stays resident until the next upload. */
+int rt_hip_upload_scene(const rt_scene* scene);
+
+/* render(c, &w) + color_convert: fills rgb_out (host memory) with this rank's
+ * rows, 3 bytes per pixel, row-major (y outer, x inner: the order in which
+ * write_canvas_to_file walks the canvas, RayTracer.c:1337-1338).
+ * rgb_out must hold rt_hip_rank_rows(...) * hsize * 3 bytes.  stats may be NULL. */
+int rt_hip_render(const rt_render_params* params, uint8_t* rgb_out, rt_stats* stats);
+
+/* Same, but rgb_out_device is device memory of the current device and the
+ * kernel is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ * library's own stream).  Nothing is copied to the host and the call does not
+ * wait for the kernel unless stats != NULL. */
+int rt_hip_render_device(const rt_render_params* params, void* rgb_out_device, void* stream,
+                         rt_stats* stats);
+
+/* The colours before quantisation: what write_pixel() stores into `canvas`
+ * (RayTracer.c:255-259), as 3 doubles per pixel, row-major (y outer).  Host
+ * memory.  For parity diagnostics. */
+int rt_hip_render_f64(const rt_render_params* params, double* canvas_out, rt_stats* stats);
+
+/* Number of image rows that belong to `rank` (see rt_render_params). */
+int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank);
+
+/* Image row held at packed row `i` of rank `rank`'s buffer. */
+int rt_hip_rank_row_to_y(int i, int band_rows, int n_ranks, int rank);
+
+/* Release device memory, stream and events. */
+void rt_hip_shutdown(void);
+
+const char* rt_hip_strerror(int status);
+/* Text of the last failing HIP call in this process ("" if none). */
+const char* rt_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

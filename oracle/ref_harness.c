@@ -1,0 +1,392 @@
+/*
+ * ref_harness.c - TEST INFRASTRUCTURE.  Drives the UNMODIFIED reference
+ * (RayTracer/RayTracer.c, found through -I at build time, never copied into
+ * this repository) at any resolution, sub-pixel pattern and stock scene.
+ *
+ * The reference ties render()/canvas/write_canvas_to_file to two 300x300
+ * macros (RayTracer.c:42-43, 255, 1574), but create_camera() takes the size at
+ * run time (RayTracer.c:1135) and ray_for_pixel()/color_at() have external
+ * linkage, so this translation unit includes the reference source as is
+ * (main renamed) and runs the same per-pixel loop as render() into its own
+ * buffer.  Nothing in the reference's arithmetic is touched.
+ *
+ * Two probes are attached from outside through a macro on the libc call
+ * qsort(): intersect_world() sorts exactly once per ray (RayTracer.c:1052), so
+ * counting qsort calls counts rays the way the survey defines them, and the
+ * array handed to qsort shows the list occupancy and exact-zero t values.
+ *
+ * Built only where the reference is present (oracle/Makefile -> oracle/_ref/).
+ */
+#include <stdint.h>
+#include <stdlib.h> /* before the macro below, so that only call sites are rewritten */
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+static uint64_t g_rays;          /* intersect_world calls */
+static uint64_t g_zero_t;        /* entries with t == 0.0 exactly (add_intersection quirk, RayTracer.c:168) */
+static size_t g_max_list;        /* largest intersection count of any ray */
+static void rt_probe_qsort(void* base, size_t n, size_t size, int (*cmp)(const void*, const void*)) {
+  ++g_rays;
+  if (n > g_max_list) g_max_list = n;
+  for (size_t i = 0; i < n; ++i) {
+    double t;
+    memcpy(&t, (char*)base + i * size, sizeof t);
+    if (t == 0.0) ++g_zero_t;
+  }
+  (qsort)(base, n, size, cmp);
+}
+#ifndef RT_REF_NO_PROBE /* the timing build leaves the libc call alone */
+#define qsort(b, n, s, c) rt_probe_qsort((b), (n), (s), (c))
+#endif
+
+#define main rt_reference_main
+#include "RayTracer.c"
+#undef main
+#undef qsort
+
+/* ---------------------------------------------------------------- scenes -- */
+/* Each builder repeats the statements of the reference's scene function with
+ * the image size as a parameter; `--stock` runs the reference's own function
+ * instead, and tests require both to give the same 300x300 canvas. */
+
+typedef struct {
+  world w;
+  camera* c;
+} scene_t;
+
+static void append_teapot_h_triangles(world* w) { /* RayTracer.c:6739-6768 */
+  struct objpar_data obj_data;
+  size_t file_size = strlen(teapot);
+  void* p_buffer = malloc(objpar_get_size(teapot, file_size));
+  unsigned int ok = objpar(teapot, file_size, p_buffer, &obj_data);
+  if (ok != 1 || obj_data.face_width != 3) { fprintf(stderr, "teapot.h parse failed\n"); exit(2); }
+  int loc = 0;
+  for (unsigned int i = 0; i < obj_data.face_count; i++) {
+    tuple p[3];
+    for (int k = 0; k < 3; ++k) {
+      unsigned int f = *(obj_data.p_faces + loc + 3 * k);
+      float x = *(obj_data.p_positions + f * obj_data.position_width - 3);
+      float y = *(obj_data.p_positions + f * obj_data.position_width - 2);
+      float z = *(obj_data.p_positions + f * obj_data.position_width - 1);
+      p[k] = create_point(x, y, z);
+    }
+    add_shape_to_world(create_triangle(p[0], p[1], p[2]), w);
+    loc += obj_data.face_width * 3;
+  }
+  free(p_buffer);
+}
+
+static scene_t scene_cube(int hs, int vs) { /* render_some_triangles, RayTracer.c:6727 */
+  scene_t s;
+  s.w = create_world();
+  s.c = create_camera(hs, vs, 0.5);
+  view_transform(create_point(10.0, 10.0, -5.0), create_point(0.0, 0.0, 0.0), create_vector(0.0, 1.0, 0.0),
+                 s.c->view_transform);
+  *s.w.lights = create_point_light(create_point(2.0, 10.0, -5.0), create_point(0.9, 0.9, 0.9));
+  append_teapot_h_triangles(&s.w);
+  return s;
+}
+
+static scene_t scene_lighthouse(int hs, int vs, const char* obj) { /* render_lighthouse_scene, RayTracer.c:6772 */
+  scene_t s;
+  s.w = create_world();
+  s.c = create_camera(hs, vs, 0.5);
+  view_transform(create_point(24.0, 18.0, -5.0), create_point(0.0, 2.1, 0.0), create_vector(0.0, 1.0, 0.0),
+                 s.c->view_transform);
+  *s.w.lights = create_point_light(create_point(2.0, 10.0, -5.0), create_point(0.9, 0.9, 0.9));
+  load_model_file((char*)obj, &s.w);
+  return s;
+}
+
+static void append_complete_world_spheres(world* w) { /* render_complete_world, RayTracer.c:5852-6163 */
+  shape* floor = create_shape(SPHERE);
+  Mat4x4 floor_transform;
+  gen_scale_matrix(10.0, 0.01, 10.0, floor_transform);
+  mat4x4_mul_in_place(floor_transform, floor->transform, floor->transform);
+  material floor_material = create_material_default();
+  floor_material.color = create_point(0.9, 0.9, 0.9);
+  floor_material.specular = 0.0;
+  floor->material = floor_material;
+
+  shape* left_wall = create_shape(SPHERE);
+  Mat4x4 translate_left, rotate_y_left, rotate_x_left, scale_left, m;
+  floor_material.color = create_point(1.0, 0.0, 0.0);
+  left_wall->material = floor_material;
+  gen_translate_matrix(0.0, 0.0, 5.0, translate_left);
+  gen_rotate_matrix_Y(-M_PI / 4.0, rotate_y_left);
+  gen_rotate_matrix_X(M_PI / 2.0, rotate_x_left);
+  gen_scale_matrix(10.0, 0.01, 10.0, scale_left);
+  mat4x4_set_ident(m);
+  mat4x4_mul_in_place(translate_left, m, m);
+  mat4x4_mul_in_place(m, rotate_y_left, m);
+  mat4x4_mul_in_place(m, rotate_x_left, m);
+  mat4x4_mul_in_place(m, scale_left, m);
+  mat4x4_copy(m, left_wall->transform);
+
+  shape* right_wall = create_shape(SPHERE); /* keeps the default material, RayTracer.c:6032-6044 */
+  floor_material.color = create_point(0.0, 0.0, 1.0);
+  Mat4x4 rotate_y_right;
+  mat4x4_set_ident(m);
+  mat4x4_mul_in_place(m, translate_left, m);
+  gen_rotate_matrix_Y(M_PI / 4.0, rotate_y_right);
+  mat4x4_mul_in_place(m, rotate_y_right, m);
+  mat4x4_mul_in_place(m, rotate_x_left, m);
+  mat4x4_mul_in_place(m, scale_left, m);
+  mat4x4_copy(m, right_wall->transform);
+  left_wall->material = floor_material; /* the blue material lands on the LEFT wall */
+
+  shape* middle = create_shape(SPHERE);
+  Mat4x4 t1;
+  gen_translate_matrix(-0.5, 1.0, 0.5, t1);
+  mat4x4_copy(t1, middle->transform);
+  material mm = create_material_default();
+  mm.color = create_point(0.1, 1.0, 0.5);
+  mm.diffuse = 0.7;
+  mm.specular = 0.3;
+  middle->material = mm;
+
+  shape* right = create_shape(SPHERE);
+  Mat4x4 tr, sr;
+  gen_translate_matrix(1.5, 0.5, -0.5, tr);
+  gen_scale_matrix(0.5, 0.5, 0.5, sr);
+  mat4x4_set_ident(m);
+  mat4x4_mul_in_place(m, tr, m);
+  mat4x4_mul_in_place(m, sr, m);
+  mat4x4_copy(m, right->transform);
+  material rm = create_material_default();
+  rm.color = create_point(0.5, 1.0, 0.1);
+  rm.diffuse = 0.7;
+  rm.specular = 0.3;
+  right->material = rm;
+
+  shape* small = create_shape(SPHERE);
+  Mat4x4 ts, ss;
+  gen_translate_matrix(-1.5, 0.33, -0.75, ts);
+  gen_scale_matrix(0.33, 0.33, 0.33, ss);
+  mat4x4_set_ident(m);
+  mat4x4_mul_in_place(m, ts, m);
+  mat4x4_mul_in_place(m, ss, m);
+  mat4x4_copy(m, small->transform);
+  material sm = create_material_default();
+  sm.color = create_point(1.0, 0.8f, 0.1);
+  sm.diffuse = 0.7;
+  sm.specular = 0.3;
+  small->material = sm;
+
+  add_shape_to_world(floor, w);
+  add_shape_to_world(left_wall, w);
+  add_shape_to_world(right_wall, w);
+  add_shape_to_world(middle, w);
+  add_shape_to_world(right, w);
+  add_shape_to_world(small, w);
+}
+
+static scene_t scene_spheres(int hs, int vs) { /* render_complete_world, RayTracer.c:5848, 6205-6213 */
+  scene_t s;
+  s.w = create_world();
+  append_complete_world_spheres(&s.w);
+  *s.w.lights = create_point_light(create_point(-10.0, 10.0, -10.0), create_point(1.0, 1.0, 1.0));
+  s.c = create_camera(hs, vs, M_PI / 3.0);
+  view_transform(create_point(0.0, 1.5, -5.0), create_point(0.0, 1.0, 0.0), create_vector(0.0, 1.0, 0.0),
+                 s.c->view_transform);
+  return s;
+}
+
+/* teapot.h mesh + the six spheres in one world: spheres first, then triangles. */
+static scene_t scene_cube_spheres(int hs, int vs) {
+  scene_t s = scene_spheres(hs, vs);
+  append_teapot_h_triangles(&s.w);
+  return s;
+}
+
+/* ------------------------------------------------------------------ dump -- */
+static void put(FILE* f, const void* p, size_t n) {
+  if (fwrite(p, 1, n, f) != n) { perror("fwrite"); exit(2); }
+}
+static void put_tuple(FILE* f, tuple t) { put(f, &t, sizeof t); }
+
+/* Scene description as the reference holds it, plus the loop invariants the
+ * reference recomputes per ray, evaluated here by the reference's own
+ * mat4x4_inverse (RayTracer.c:601).  Layout is read by tests/refdump.py. */
+static void dump_scene(const char* path, scene_t* s) {
+  FILE* f = fopen(path, "wb");
+  if (!f) { perror(path); exit(2); }
+  put(f, "RTSCENE1", 8);
+  int32_t hv[2] = {(int32_t)s->c->hsize, (int32_t)s->c->vsize};
+  put(f, hv, sizeof hv);
+  double cam[4] = {s->c->field_of_view, s->c->pixel_size, s->c->half_width, s->c->half_height};
+  put(f, cam, sizeof cam);
+  put(f, s->c->view_transform, sizeof(Mat4x4));
+  Mat4x4 inv;
+  mat4x4_inverse(s->c->view_transform, inv);
+  put(f, inv, sizeof inv);
+  put_tuple(f, s->w.lights->position);
+  put_tuple(f, s->w.lights->intensity);
+  int32_t n = 0;
+  for (shape* sp = s->w.objects; sp; sp = sp->next) ++n;
+  int32_t hdr[2] = {n, 0};
+  put(f, hdr, sizeof hdr);
+  for (shape* sp = s->w.objects; sp; sp = sp->next) {
+    int32_t ty[2] = {(int32_t)sp->type, 0};
+    put(f, ty, sizeof ty);
+    put(f, sp->transform, sizeof(Mat4x4));
+    mat4x4_set_ident(inv);
+    mat4x4_inverse(sp->transform, inv);
+    put(f, inv, sizeof inv);
+    if (sp->type == TRIANGLE) {
+      put_tuple(f, sp->p1); put_tuple(f, sp->p2); put_tuple(f, sp->p3);
+      put_tuple(f, sp->e1); put_tuple(f, sp->e2); put_tuple(f, sp->normal);
+    } else {
+      tuple z = {0, 0, 0, 0};
+      for (int k = 0; k < 6; ++k) put_tuple(f, z);
+    }
+    put_tuple(f, sp->material.color);
+    double mat[7] = {sp->material.ambient, sp->material.diffuse, sp->material.specular, sp->material.shininess,
+                     sp->material.reflective, sp->material.transparency, sp->material.refractive_index};
+    put(f, mat, sizeof mat);
+  }
+  fclose(f);
+}
+
+/* ------------------------------------------------------------------ main -- */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void usage(void) {
+  fprintf(stderr,
+          "rt_ref_harness --scene lighthouse|cube|spheres|cube_spheres [--size W H] [--spp-grid G]\n"
+          "   [--tri-reflective K] [--sph-reflective K] [--obj lighthouse.obj] [--rows Y0 Y1]\n"
+          "   [--stock] [--dump-scene F] [--out-f64 F] [--out-rgb F] [--out-ppm F] [--no-render]\n");
+  exit(2);
+}
+
+int main(int argc, char** argv) {
+  const char* scene = NULL;
+  const char* obj = "lighthouse.obj";
+  const char *dump = NULL, *out_f64 = NULL, *out_rgb = NULL, *out_ppm = NULL;
+  int W = HORIZONTAL_SIZE, H = VERTICAL_SIZE, G = 1, stock = 0, no_render = 0, y0 = 0, y1 = -1;
+  double tri_refl = 0.0, sph_refl = 0.0;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
+    else if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "--spp-grid") && i + 1 < argc) G = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--tri-reflective") && i + 1 < argc) tri_refl = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--sph-reflective") && i + 1 < argc) sph_refl = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--obj") && i + 1 < argc) obj = argv[++i];
+    else if (!strcmp(argv[i], "--rows") && i + 2 < argc) { y0 = atoi(argv[++i]); y1 = atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "--stock")) stock = 1;
+    else if (!strcmp(argv[i], "--no-render")) no_render = 1;
+    else if (!strcmp(argv[i], "--dump-scene") && i + 1 < argc) dump = argv[++i];
+    else if (!strcmp(argv[i], "--out-f64") && i + 1 < argc) out_f64 = argv[++i];
+    else if (!strcmp(argv[i], "--out-rgb") && i + 1 < argc) out_rgb = argv[++i];
+    else if (!strcmp(argv[i], "--out-ppm") && i + 1 < argc) out_ppm = argv[++i];
+    else usage();
+  }
+  if (!scene || W < 1 || H < 1 || G < 1) usage();
+  contents = containers_create(); /* RayTracer.c:7048 */
+
+  double* img = NULL; /* [H][W][3] */
+  double seconds = 0.0;
+  if (stock) {
+    /* the reference's own scene function and its own render() into `canvas` */
+    if (W != HORIZONTAL_SIZE || H != VERTICAL_SIZE || G != 1) usage();
+    if (!strcmp(scene, "lighthouse")) {
+      const char* slash = strrchr(obj, '/');
+      if (slash) { /* load_model_file("lighthouse.obj") is CWD-relative, RayTracer.c:6784 */
+        char dir[4096];
+        snprintf(dir, sizeof dir, "%.*s", (int)(slash - obj), obj);
+        if (chdir(dir) != 0) { perror(dir); return 2; }
+      }
+    }
+    double t0 = now_s();
+    if (!strcmp(scene, "lighthouse")) render_lighthouse_scene();
+    else if (!strcmp(scene, "cube")) render_some_triangles();
+    else if (!strcmp(scene, "spheres")) render_complete_world();
+    else usage();
+    seconds = now_s() - t0;
+    img = malloc(sizeof(double) * 3 * W * H);
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        img[(y * W + x) * 3 + 0] = canvas[x][y].x;
+        img[(y * W + x) * 3 + 1] = canvas[x][y].y;
+        img[(y * W + x) * 3 + 2] = canvas[x][y].z;
+      }
+    y0 = 0; y1 = H;
+  } else {
+    scene_t s;
+    if (!strcmp(scene, "lighthouse")) s = scene_lighthouse(W, H, obj);
+    else if (!strcmp(scene, "cube")) s = scene_cube(W, H);
+    else if (!strcmp(scene, "spheres")) s = scene_spheres(W, H);
+    else if (!strcmp(scene, "cube_spheres")) s = scene_cube_spheres(W, H);
+    else usage();
+    for (shape* sp = s.w.objects; sp; sp = sp->next) {
+      if (sp->type == TRIANGLE && tri_refl != 0.0) sp->material.reflective = tri_refl;
+      if (sp->type == SPHERE && sph_refl != 0.0) sp->material.reflective = sph_refl;
+    }
+    if (dump) dump_scene(dump, &s);
+    if (y1 < 0 || y1 > H) y1 = H;
+    if (!no_render) {
+      img = calloc((size_t)3 * W * H, sizeof(double));
+      g_rays = 0;
+      double t0 = now_s();
+      for (int y = y0; y < y1; ++y) {
+        for (int x = 0; x < W; ++x) {
+          double sx = 0.0, sy = 0.0, sz = 0.0;
+          for (int j = 0; j < G; ++j) {
+            for (int i = 0; i < G; ++i) {
+              /* G == 1 gives px = x exactly: the reference's render() loop, RayTracer.c:1576-1587 */
+              double px = x + (i + 0.5) / G - 0.5;
+              double py = y + (j + 0.5) / G - 0.5;
+              ray r = ray_for_pixel(s.c, px, py);
+              tuple col = color_at(&s.w, &r, RECURSION_DEPTH);
+              sx += col.x; sy += col.y; sz += col.z;
+            }
+          }
+          double n = (double)(G * G);
+          img[(y * W + x) * 3 + 0] = sx / n;
+          img[(y * W + x) * 3 + 1] = sy / n;
+          img[(y * W + x) * 3 + 2] = sz / n;
+        }
+      }
+      seconds = now_s() - t0;
+    }
+  }
+
+  if (img && out_f64) {
+    FILE* f = fopen(out_f64, "wb");
+    if (!f) { perror(out_f64); return 2; }
+    put(f, img, sizeof(double) * 3 * W * H);
+    fclose(f);
+  }
+  if (img && out_rgb) {
+    FILE* f = fopen(out_rgb, "wb");
+    if (!f) { perror(out_rgb); return 2; }
+    for (size_t k = 0; k < (size_t)3 * W * H; ++k) {
+      unsigned char b = (unsigned char)color_convert(img[k]);
+      put(f, &b, 1);
+    }
+    fclose(f);
+  }
+  if (img && out_ppm) { /* same bytes as write_canvas_to_file, RayTracer.c:1333-1348 */
+    FILE* f = fopen(out_ppm, "w");
+    if (!f) { perror(out_ppm); return 2; }
+    fprintf(f, "P3\n");
+    fprintf(f, "%d %d\n255\n", W, H);
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 0]));
+        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 1]));
+        fprintf(f, "%d \n", color_convert(img[(y * W + x) * 3 + 2]));
+      }
+    fclose(f);
+  }
+  printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"rows\": [%d, %d], \"stock\": %d, "
+         "\"rays\": %llu, \"max_list\": %zu, \"exact_zero_t\": %llu, \"seconds\": %.6f}\n",
+         scene, W, H, G, y0, y1, stock, (unsigned long long)g_rays, g_max_list, (unsigned long long)g_zero_t, seconds);
+  return 0;
+}
