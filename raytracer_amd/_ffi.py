@@ -162,6 +162,12 @@ def hip_lib():
         path = os.path.join(LIB_DIR, "librt_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C raytracer_amd` (or __graft_entry__.build())")
+        # PyTorch ships its own libamdhip64.so.7.  A process must hold ONE HIP runtime: load torch's first so
+        # that this library's NEEDED libamdhip64.so.7 resolves to the copy torch (device memory, RCCL) uses.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.rt_hip_init.argtypes = [C.c_int]
         L.rt_hip_upload_scene.argtypes = [C.POINTER(Scene)]

@@ -1,0 +1,397 @@
+/*
+ * rt_api.hip - implementation of the C ABI in include/rt_hip.h.
+ *
+ * Replaces the call render(camera*, world*) of the reference
+ * (RayTracer/RayTracer.c:1574): rt_hip_upload_scene takes the flattened world
+ * once, rt_hip_render runs the trace kernels of rt_kernels.hip.inc over the
+ * image and returns the quantised pixels.
+ */
+#include "rt_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_kernels.hip.inc"
+
+namespace {
+
+struct Context {
+  bool ready = false;
+  bool have_scene = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevScene scene{};
+  bool reflective = false;
+  void* d_spheres = nullptr;
+  void* d_tris = nullptr;
+  void* d_normals = nullptr;
+  void* d_materials = nullptr;
+  void* d_bvh = nullptr;
+  unsigned long long* d_counters = nullptr;
+  unsigned char* d_rgb = nullptr;  /* library-owned output for rt_hip_render */
+  size_t d_rgb_bytes = 0;
+  double* d_canvas = nullptr;
+  size_t d_canvas_bytes = 0;
+};
+
+Context g;
+char g_err[512] = "";
+
+bool hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return false;
+}
+#define HIP_TRY(call)                       \
+  do {                                      \
+    if (!hip_ok((call), #call)) return RT_ERR_HIP; \
+  } while (0)
+
+void free_scene() {
+  if (g.d_spheres) (void)hipFree(g.d_spheres);
+  if (g.d_tris) (void)hipFree(g.d_tris);
+  if (g.d_normals) (void)hipFree(g.d_normals);
+  if (g.d_materials) (void)hipFree(g.d_materials);
+  if (g.d_bvh) (void)hipFree(g.d_bvh);
+  g.d_spheres = g.d_tris = g.d_normals = g.d_materials = g.d_bvh = nullptr;
+  g.have_scene = false;
+}
+
+int upload(void** dst, const void* src, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(hipMalloc(dst, bytes));
+  if (src) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
+  if (i < 0 || i >= n || guard > 4096) return 1 << 20;
+  if (nodes[i].right < 0) return 1;
+  if (nodes[i].left <= i || nodes[i].right <= i) return 1 << 20; /* children come after their parent */
+  const int l = bvh_depth(nodes, n, nodes[i].left, guard + 1), r = bvh_depth(nodes, n, nodes[i].right, guard + 1);
+  return 1 + (l > r ? l : r);
+}
+
+template <bool COUNT, bool BVH, bool REFLECT>
+void launch_f64(bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  if (f64)
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, true>), grid, dim3(RT_TILE_W * RT_TILE_H), 0, s, g.scene, a,
+                       rgb, canvas, g.d_counters);
+  else
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, false>), grid, dim3(RT_TILE_W * RT_TILE_H), 0, s, g.scene,
+                       a, rgb, canvas, g.d_counters);
+}
+template <bool COUNT, bool BVH>
+void launch_refl(bool reflect, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+                 double* canvas) {
+  if (reflect) launch_f64<COUNT, BVH, true>(f64, grid, s, a, rgb, canvas);
+  else launch_f64<COUNT, BVH, false>(f64, grid, s, a, rgb, canvas);
+}
+void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a,
+            unsigned char* rgb, double* canvas) {
+  if (count) {
+    if (bvh) launch_refl<true, true>(reflect, f64, grid, s, a, rgb, canvas);
+    else launch_refl<true, false>(reflect, f64, grid, s, a, rgb, canvas);
+  } else {
+    if (bvh) launch_refl<false, true>(reflect, f64, grid, s, a, rgb, canvas);
+    else launch_refl<false, false>(reflect, f64, grid, s, a, rgb, canvas);
+  }
+}
+
+int check_params(const rt_render_params* p) {
+  if (!p) return RT_ERR_INVALID;
+  if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
+  if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH) return RT_ERR_TOO_LARGE;
+  if (p->spp_grid < 1 || p->spp_grid > 64) return RT_ERR_INVALID;
+  if (p->n_ranks < 1 || p->rank < 0 || p->rank >= p->n_ranks) return RT_ERR_INVALID;
+  if (p->n_ranks > 1 && p->band_rows < 1) return RT_ERR_INVALID;
+  if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH) return RT_ERR_INVALID;
+  if (p->accel == RT_ACCEL_BVH && g.scene.n_bvh_nodes == 0 && g.scene.n_tris > 0) return RT_ERR_NOT_READY;
+  return RT_OK;
+}
+
+/* enqueue one render on `s`; waits and fills stats only when stats != NULL */
+int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats) {
+  const int W = g.scene.hsize, H = g.scene.vsize;
+  const int rows = rt_hip_rank_rows(H, p->band_rows, p->n_ranks, p->rank);
+  RenderArgs a;
+  a.max_depth = p->max_depth;
+  a.spp_grid = p->spp_grid;
+  a.band_rows = p->n_ranks > 1 ? p->band_rows : 1;
+  a.n_ranks = p->n_ranks;
+  a.rank = p->rank;
+  a.rows = rows;
+  bool bvh = g.scene.n_bvh_nodes > 0 && g.scene.n_tris > 0;
+  if (p->accel == RT_ACCEL_BRUTE) bvh = false;
+  if (p->accel == RT_ACCEL_AUTO && g.scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
+  const bool count = p->count_rays != 0 && stats != nullptr;
+  const bool reflect = g.reflective && p->max_depth >= 1;
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (rows > 0) {
+    if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 5 * sizeof(unsigned long long), s));
+    dim3 grid((unsigned)((W + RT_TILE_W - 1) / RT_TILE_W), (unsigned)((rows + RT_TILE_H - 1) / RT_TILE_H));
+    if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
+    launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
+    HIP_TRY(hipGetLastError());
+    if (stats) HIP_TRY(hipEventRecord(g.ev1, s));
+  }
+  if (stats) {
+    stats->rows_rendered = rows;
+    stats->accel_used = bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE;
+    if (rows > 0) {
+      HIP_TRY(hipEventSynchronize(g.ev1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+      stats->kernel_ms = ms;
+      if (count) {
+        unsigned long long c[5];
+        HIP_TRY(hipMemcpyAsync(c, g.d_counters, sizeof c, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        stats->rays_primary = c[0];
+        stats->rays_shadow = c[1];
+        stats->rays_secondary = c[2];
+        stats->prim_tests = c[3];
+        stats->node_tests = c[4];
+      }
+    }
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_hip_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+    snprintf(g_err, sizeof g_err, "no HIP device");
+    return RT_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) return RT_ERR_NO_DEVICE;
+  if (g.ready && g.device == device) return RT_OK;
+  if (g.ready) rt_hip_shutdown();
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&g.ev0));
+  HIP_TRY(hipEventCreate(&g.ev1));
+  HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
+  g.device = device;
+  g.ready = true;
+  return RT_OK;
+}
+
+int rt_hip_upload_scene(const rt_scene* sc) {
+  if (!sc) return RT_ERR_INVALID;
+  if (!g.ready) return RT_ERR_NOT_READY;
+  if (sc->camera.hsize < 1 || sc->camera.vsize < 1 || sc->n_spheres < 0 || sc->n_tris < 0 || sc->n_materials < 0)
+    return RT_ERR_INVALID;
+  /* an empty world is legal (every pixel black); anything else needs its materials */
+  if (sc->n_spheres + sc->n_tris > 0 && (sc->n_materials < 1 || !sc->materials)) return RT_ERR_INVALID;
+  if ((sc->n_spheres && (!sc->sph_inv || !sc->sph_material || !sc->sph_order)) ||
+      (sc->n_tris && (!sc->tri_soa || !sc->tri_material || !sc->tri_order)))
+    return RT_ERR_INVALID;
+  if ((long long)sc->camera.hsize * sc->camera.vsize > (1ll << 31) / 3) return RT_ERR_TOO_LARGE;
+  const int ns = sc->n_spheres, nt = sc->n_tris;
+  const int n_prims = ns + nt;
+
+  /* validate: material indices, list positions form a permutation, affine inverses */
+  std::vector<char> seen((size_t)(n_prims > 0 ? n_prims : 1), 0);
+  for (int i = 0; i < ns; ++i) {
+    const double* m = sc->sph_inv + 16 * (size_t)i;
+    if (m[12] != 0.0 || m[13] != 0.0 || m[14] != 0.0 || m[15] != 1.0) return RT_ERR_UNSUPPORTED;
+    if (sc->sph_material[i] < 0 || sc->sph_material[i] >= sc->n_materials) return RT_ERR_INVALID;
+    const int k = sc->sph_order[i];
+    if (k < 0 || k >= n_prims || seen[k]) return RT_ERR_INVALID;
+    seen[k] = 1;
+  }
+  for (int i = 0; i < nt; ++i) {
+    if (sc->tri_material[i] < 0 || sc->tri_material[i] >= sc->n_materials) return RT_ERR_INVALID;
+    const int k = sc->tri_order[i];
+    if (k < 0 || k >= n_prims || seen[k]) return RT_ERR_INVALID;
+    seen[k] = 1;
+  }
+  bool use_bvh = sc->n_bvh_nodes > 0 && sc->bvh_nodes && sc->bvh_tri && nt > 0;
+  int depth = 0;
+  if (use_bvh) {
+    depth = bvh_depth(sc->bvh_nodes, sc->n_bvh_nodes, 0, 0);
+    if (depth > RT_BVH_STACK) return RT_ERR_TOO_LARGE;
+    std::vector<char> used((size_t)nt, 0);
+    for (int i = 0; i < sc->n_bvh_nodes; ++i) {
+      const rt_bvh_node& n = sc->bvh_nodes[i];
+      if (n.right < 0) {
+        if (n.left < 0 || (long long)n.left - n.right > nt) return RT_ERR_INVALID;
+      } else if (n.left <= 0 || n.left >= sc->n_bvh_nodes || n.right <= 0 || n.right >= sc->n_bvh_nodes) {
+        return RT_ERR_INVALID;
+      }
+    }
+    for (int i = 0; i < nt; ++i) {
+      const int t = sc->bvh_tri[i];
+      if (t < 0 || t >= nt || used[t]) return RT_ERR_INVALID;
+      used[t] = 1;
+    }
+  }
+
+  free_scene();
+  std::vector<DevSphere> hs((size_t)(ns > 0 ? ns : 1));
+  for (int i = 0; i < ns; ++i) {
+    memcpy(hs[i].inv, sc->sph_inv + 16 * (size_t)i, 12 * sizeof(double));
+    hs[i].material = sc->sph_material[i];
+    hs[i].order = sc->sph_order[i];
+  }
+  std::vector<DevTri> ht((size_t)(nt > 0 ? nt : 1));
+  std::vector<double> hn((size_t)(nt > 0 ? nt : 1) * 3);
+  for (int k = 0; k < nt; ++k) {
+    const int i = use_bvh ? sc->bvh_tri[k] : k; /* device order = BVH leaf order */
+    for (int c = 0; c < 3; ++c) {
+      ht[k].p1[c] = sc->tri_soa[(size_t)(0 + c) * nt + i];
+      ht[k].e1[c] = sc->tri_soa[(size_t)(3 + c) * nt + i];
+      ht[k].e2[c] = sc->tri_soa[(size_t)(6 + c) * nt + i];
+      hn[3 * (size_t)k + c] = sc->tri_soa[(size_t)(9 + c) * nt + i];
+    }
+    ht[k].material = sc->tri_material[i];
+    ht[k].order = sc->tri_order[i];
+  }
+  int rc;
+  if ((rc = upload(&g.d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
+  if ((rc = upload(&g.d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&g.d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&g.d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
+  if (use_bvh &&
+      (rc = upload(&g.d_bvh, sc->bvh_nodes, sizeof(rt_bvh_node) * (size_t)sc->n_bvh_nodes)) != RT_OK)
+    return rc;
+
+  DevScene& d = g.scene;
+  d.pixel_size = sc->camera.pixel_size;
+  d.half_width = sc->camera.half_width;
+  d.half_height = sc->camera.half_height;
+  memcpy(d.inv_view, sc->camera.inv_view, 12 * sizeof(double));
+  /* inv_view * point(0,0,0), mat4x4_mul_tuple order (RayTracer.c:419, 1563) */
+  for (int r = 0; r < 3; ++r) {
+    const double* m = sc->camera.inv_view + 4 * r;
+    d.origin[r] = ((0.0 * m[0] + 0.0 * m[1]) + 0.0 * m[2]) + 1.0 * m[3];
+  }
+  memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
+  memcpy(d.light_int, sc->light.intensity, sizeof d.light_int);
+  d.hsize = sc->camera.hsize;
+  d.vsize = sc->camera.vsize;
+  d.n_spheres = ns;
+  d.n_tris = nt;
+  d.n_bvh_nodes = use_bvh ? sc->n_bvh_nodes : 0;
+  d.bvh_depth = depth;
+  d.spheres = (const DevSphere*)g.d_spheres;
+  d.tris = (const DevTri*)g.d_tris;
+  d.tri_normals = (const double*)g.d_normals;
+  d.materials = (const rt_material*)g.d_materials;
+  d.bvh = (const rt_bvh_node*)g.d_bvh;
+  g.reflective = false;
+  for (int i = 0; i < sc->n_materials; ++i)
+    if (!(std::fabs(sc->materials[i].reflective - 0.0) < RT_EPSILON)) g.reflective = true;
+  g.have_scene = true;
+  return RT_OK;
+}
+
+int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank) {
+  if (vsize < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return RT_ERR_INVALID;
+  if (n_ranks == 1) return vsize;
+  if (band_rows < 1) return RT_ERR_INVALID;
+  const int stride = band_rows * n_ranks;
+  const int full = vsize / stride, rem = vsize % stride;
+  int rows = full * band_rows;
+  const int start = rank * band_rows;
+  if (rem > start) rows += (rem - start < band_rows) ? rem - start : band_rows;
+  return rows;
+}
+
+int rt_hip_rank_row_to_y(int i, int band_rows, int n_ranks, int rank) {
+  if (i < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return RT_ERR_INVALID;
+  if (n_ranks == 1) return i;
+  if (band_rows < 1) return RT_ERR_INVALID;
+  const int band = i / band_rows;
+  return (band * n_ranks + rank) * band_rows + i % band_rows;
+}
+
+int rt_hip_render_device(const rt_render_params* p, void* rgb_out_device, void* stream, rt_stats* stats) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  if (!rgb_out_device) return RT_ERR_INVALID;
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  return render_common(p, (unsigned char*)rgb_out_device, nullptr, s, stats);
+}
+
+int rt_hip_render(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  if (!rgb_out) return RT_ERR_INVALID;
+  const int rows = rt_hip_rank_rows(g.scene.vsize, p->band_rows, p->n_ranks, p->rank);
+  const size_t bytes = (size_t)rows * g.scene.hsize * 3;
+  if (bytes > g.d_rgb_bytes) {
+    if (g.d_rgb) (void)hipFree(g.d_rgb);
+    g.d_rgb = nullptr;
+    g.d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_rgb, bytes));
+    g.d_rgb_bytes = bytes;
+  }
+  rc = render_common(p, g.d_rgb, nullptr, g.stream, stats);
+  if (rc != RT_OK) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(rgb_out, g.d_rgb, bytes, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return RT_OK;
+}
+
+int rt_hip_render_f64(const rt_render_params* p, double* canvas_out, rt_stats* stats) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  if (!canvas_out) return RT_ERR_INVALID;
+  const int rows = rt_hip_rank_rows(g.scene.vsize, p->band_rows, p->n_ranks, p->rank);
+  const size_t bytes = (size_t)rows * g.scene.hsize * 3 * sizeof(double);
+  if (bytes > g.d_canvas_bytes) {
+    if (g.d_canvas) (void)hipFree(g.d_canvas);
+    g.d_canvas = nullptr;
+    g.d_canvas_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_canvas, bytes));
+    g.d_canvas_bytes = bytes;
+  }
+  rc = render_common(p, nullptr, g.d_canvas, g.stream, stats);
+  if (rc != RT_OK) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(canvas_out, g.d_canvas, bytes, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return RT_OK;
+}
+
+void rt_hip_shutdown(void) {
+  if (!g.ready) return;
+  (void)hipSetDevice(g.device);
+  (void)hipStreamSynchronize(g.stream);
+  free_scene();
+  if (g.d_counters) (void)hipFree(g.d_counters);
+  if (g.d_rgb) (void)hipFree(g.d_rgb);
+  if (g.d_canvas) (void)hipFree(g.d_canvas);
+  if (g.ev0) (void)hipEventDestroy(g.ev0);
+  if (g.ev1) (void)hipEventDestroy(g.ev1);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+  g = Context{};
+}
+
+const char* rt_hip_strerror(int status) {
+  switch (status) {
+    case RT_OK: return "ok";
+    case RT_ERR_INVALID: return "invalid argument";
+    case RT_ERR_NO_DEVICE: return "no such HIP device";
+    case RT_ERR_HIP: return "HIP runtime error";
+    case RT_ERR_UNSUPPORTED: return "scene uses a feature outside the accelerated path";
+    case RT_ERR_NOT_READY: return "rt_hip_init / rt_hip_upload_scene not called";
+    case RT_ERR_TOO_LARGE: return "scene or image exceeds a library limit";
+    default: return "unknown status";
+  }
+}
+
+const char* rt_hip_last_error(void) { return g_err; }
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+/*
+ * rt_device_math.h - double-precision 3-vector helpers for the gfx950 kernels,
+ * each with the operation order of the reference's tuple functions
+ * (RayTracer/RayTracer.c:304-365, 419-424, 1065-1069).
+ *
+ * The reference carries a 4th lane w through every tuple operation.  On this
+ * path w is exactly 0 for vectors and exactly 1 for points (the host rejects
+ * non-affine transforms), so the w products are exact zeros and adding them
+ * cannot change a sum; they are left out here.
+ *
+ * Compile with -ffp-contract=off: a*b+c must round twice, as it does in the
+ * reference's x86-64 SSE2 code.
+ */
+#ifndef RT_DEVICE_MATH_H
+#define RT_DEVICE_MATH_H
+
+#include <hip/hip_runtime.h>
+
+struct d3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ d3 mk3(double x, double y, double z) {
+  d3 r;
+  r.x = x; r.y = y; r.z = z;
+  return r;
+}
+__device__ __forceinline__ d3 add3(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }   /* :304 */
+__device__ __forceinline__ d3 sub3(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }   /* :309 */
+__device__ __forceinline__ d3 neg3(d3 a) { return mk3(0.0 - a.x, 0.0 - a.y, 0.0 - a.z); }          /* :314 */
+__device__ __forceinline__ d3 scale3(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }    /* :320 */
+__device__ __forceinline__ d3 mul3(d3 a, d3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }    /* :330 */
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } /* :350 */
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {                                                 /* :359 */
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double mag3(d3 a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); } /* :335 */
+__device__ __forceinline__ d3 normalize3(d3 a) {                                                   /* :344 */
+  const double m = mag3(a);
+  return mk3(a.x / m, a.y / m, a.z / m);
+}
+__device__ __forceinline__ d3 reflect3(d3 in, d3 n) {                                              /* :1065 */
+  const d3 two_n = scale3(n, 2.0);
+  const double d = dot3(in, n);
+  return sub3(in, scale3(two_n, d));
+}
+
+/* rows 0..2 of a row-major 4x4 whose bottom row is 0 0 0 1 (mat4x4_mul_tuple, :419) */
+__device__ __forceinline__ d3 xform_point(const double* __restrict__ m, d3 p) { /* w == 1: 1 * m[3] == m[3] */
+  return mk3(((p.x * m[0] + p.y * m[1]) + p.z * m[2]) + m[3], ((p.x * m[4] + p.y * m[5]) + p.z * m[6]) + m[7],
+             ((p.x * m[8] + p.y * m[9]) + p.z * m[10]) + m[11]);
+}
+__device__ __forceinline__ d3 xform_vector(const double* __restrict__ m, d3 v) { /* w == 0 */
+  return mk3((v.x * m[0] + v.y * m[1]) + v.z * m[2], (v.x * m[4] + v.y * m[5]) + v.z * m[6],
+             (v.x * m[8] + v.y * m[9]) + v.z * m[10]);
+}
+/* transpose(m) * v with w == 0 (normal_at_shape_sphere_plane, :743-744) */
+__device__ __forceinline__ d3 xform_vector_transposed(const double* __restrict__ m, d3 v) {
+  return mk3((v.x * m[0] + v.y * m[4]) + v.z * m[8], (v.x * m[1] + v.y * m[5]) + v.z * m[9],
+             (v.x * m[2] + v.y * m[6]) + v.z * m[10]);
+}
+
+#endif

@@ -1,0 +1,96 @@
+"""Python handle on the C ABI of librt_hip.so (include/rt_hip.h).
+
+Plumbing only: every call goes straight to the HIP library; there is no CPU
+fallback and a missing library or device raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import RenderParams, Stats
+
+
+class RtError(RuntimeError):
+    def __init__(self, what, rc):
+        L = _ffi.hip_lib()
+        msg = L.rt_hip_strerror(rc).decode()
+        detail = L.rt_hip_last_error().decode()
+        super().__init__(f"{what}: {msg} ({rc})" + (f" [{detail}]" if detail else ""))
+        self.status = rc
+
+
+def _check(rc, what):
+    if rc != _ffi.RT_OK:
+        raise RtError(what, rc)
+
+
+def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0):
+    return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, 0)
+
+
+class HipRenderer:
+    """One process, one GPU: init -> upload(scene) -> render*()."""
+
+    def __init__(self, device=0):
+        self._L = _ffi.hip_lib()
+        _check(self._L.rt_hip_init(int(device)), "rt_hip_init")
+        self.device = int(device)
+        self._scene = None
+
+    def upload(self, scene):
+        _check(self._L.rt_hip_upload_scene(C.byref(scene)), "rt_hip_upload_scene")
+        self._scene = scene  # keeps the host arrays alive; the device copy is independent
+        self.width, self.height = scene.camera.hsize, scene.camera.vsize
+        return self
+
+    def rank_rows(self, p):
+        n = self._L.rt_hip_rank_rows(self.height, p.band_rows, p.n_ranks, p.rank)
+        if n < 0:
+            raise RtError("rt_hip_rank_rows", n)
+        return n
+
+    def render(self, params=None, stats=True, **kw):
+        """Host image: uint8 [rows, width, 3] of this rank's rows."""
+        p = params or make_params(**kw)
+        out = np.empty((self.rank_rows(p), self.width, 3), dtype=np.uint8)
+        st = Stats()
+        _check(self._L.rt_hip_render(C.byref(p), out.ctypes.data, C.byref(st) if stats else None), "rt_hip_render")
+        return out, st
+
+    def render_f64(self, params=None, **kw):
+        p = params or make_params(**kw)
+        out = np.empty((self.rank_rows(p), self.width, 3), dtype=np.float64)
+        st = Stats()
+        _check(self._L.rt_hip_render_f64(C.byref(p), out.ctypes.data, C.byref(st)), "rt_hip_render_f64")
+        return out, st
+
+    def render_device(self, data_ptr, params, stream=None, stats=None):
+        """Enqueue a render into device memory at `data_ptr` (e.g. a torch uint8 tensor's data_ptr())."""
+        _check(
+            self._L.rt_hip_render_device(
+                C.byref(params), C.c_void_p(data_ptr), C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None
+            ),
+            "rt_hip_render_device",
+        )
+
+    def shutdown(self):
+        self._L.rt_hip_shutdown()
+
+
+def rank_row_map(height, band_rows, n_ranks, rank):
+    """Image rows owned by `rank`, in packed order."""
+    L = _ffi.hip_lib()
+    n = L.rt_hip_rank_rows(height, band_rows, n_ranks, rank)
+    return np.array([L.rt_hip_rank_row_to_y(i, band_rows, n_ranks, rank) for i in range(n)], dtype=np.int64)
+
+
+def ppm_bytes(rgb):
+    """ASCII P3 bytes identical to the reference's write_canvas_to_file (RayTracer.c:1333)."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = a.shape
+    L = _ffi.host_lib()
+    need = L.rt_format_ppm(None, 0, a.ctypes.data, w, h)
+    buf = C.create_string_buffer(need)
+    got = L.rt_format_ppm(buf, need, a.ctypes.data, w, h)
+    return buf.raw[:got]

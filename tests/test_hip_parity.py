@@ -1,0 +1,160 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden images.
+
+Bar (north star): >= 99.9 % of pixels identical, no channel off by more than 1.
+The double-precision canvas is additionally required to agree to 1e-12 relative:
+the kernels evaluate the reference's expressions in the reference's order, and
+only pow() may differ in its last bits.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytracer_amd as R
+from conftest import load_golden, quantise
+
+pytestmark = pytest.mark.gpu
+
+ACCELS = [R._ffi.RT_ACCEL_BRUTE, R._ffi.RT_ACCEL_BVH]
+
+
+def assert_image_parity(got, want, what):
+    assert got.shape == want.shape, what
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    npx = got.shape[0] * got.shape[1]
+    exact = int((diff.max(axis=2) == 0).sum())
+    assert diff.max() <= 1, f"{what}: a channel differs by {diff.max()}"
+    assert exact >= 0.999 * npx, f"{what}: only {exact}/{npx} pixels identical"
+    return exact, npx
+
+
+def scene_for(e, **kw):
+    return R.stock_scene(e["scene"], e["width"], e["height"], e["tri_reflective"], e["sph_reflective"], **kw)
+
+
+SMALL = [
+    "lighthouse_96x64", "cube_96x64", "spheres_96x64", "cube_spheres_96x64", "lighthouse_refl_96x64",
+    "cube_spheres_refl_96x64", "cube_spheres_ss4_48x32", "spheres_ss2_48x32", "cube_101x37", "spheres_33x71",
+]
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("name", SMALL)
+def test_canvas_matches_reference_canvas(hip, manifest, name, accel):
+    """Double canvas of the HIP path vs the canvas the reference itself produced."""
+    e = manifest[name]
+    hip.upload(scene_for(e))
+    got, st = hip.render_f64(spp_grid=e["spp_grid"], accel=accel, count_rays=True)
+    want = load_golden(e, "canvas")
+    assert st.rays == e["rays"], "ray count (intersect_world calls)"
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+    ex, npx = assert_image_parity(quantise(got), quantise(want), name)
+    assert ex == npx
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("name", ["lighthouse_300", "cube_300", "spheres_300", "lighthouse_refl_320x180"])
+def test_reference_images_300(hip, manifest, name, accel):
+    """The reference's own scenes at its built-in resolution; the PPM must hash to the reference's file."""
+    e = manifest[name]
+    hip.upload(scene_for(e))
+    got, st = hip.render(accel=accel, count_rays=True)
+    want = load_golden(e, "rgb")
+    assert_image_parity(got, want, name)
+    assert st.rays == e["rays"]
+    if np.array_equal(got, want):
+        assert hashlib.sha256(R.ppm_bytes(got)).hexdigest() == e["ppm_sha256"]
+
+
+@pytest.mark.parametrize("name", ["lighthouse_1080p", "cube_1080p", "spheres_1080p"])
+def test_reference_images_1080p(hip, manifest, name):
+    """Full BASELINE sizes against the reference's 1920x1080 images."""
+    e = manifest[name]
+    hip.upload(scene_for(e))
+    got, st = hip.render(count_rays=True)
+    want = load_golden(e, "rgb")
+    ex, npx = assert_image_parity(got, want, name)
+    assert st.rays == e["rays"]
+    print(f"{name}: {ex}/{npx} identical, kernel {st.kernel_ms:.3f} ms, {st.rays / st.kernel_ms / 1e3:.1f} Mrays/s")
+
+
+def random_scene(seed, w, h, n_spheres, n_tris, reflective):
+    rng = np.random.default_rng(seed)
+    b = R.SceneBuilder()
+    b.set_camera(w, h, 0.9, (0.0, 1.0, -8.0), (0.0, 0.5, 0.0))
+    b.set_light((-6.0, 9.0, -7.0), (1.0, 0.95, 0.9))
+    for _ in range(n_spheres):
+        m = R.default_material(color=rng.uniform(0.1, 1.0, 3), diffuse=rng.uniform(0.4, 0.9),
+                               specular=rng.uniform(0.0, 0.9), shininess=rng.uniform(5, 300),
+                               reflective=rng.choice([0.0, reflective]))
+        t = R.Mat4.mul(R.Mat4.translate(*rng.uniform(-3, 3, 3)), R.Mat4.mul(R.Mat4.rotate_y(rng.uniform(0, 3)),
+                       R.Mat4.scale(*rng.uniform(0.3, 1.5, 3))))
+        b.add_sphere(t, m)
+    for _ in range(n_tris):
+        c = rng.uniform(-3, 3, 3)
+        m = R.default_material(color=rng.uniform(0.1, 1.0, 3), reflective=rng.choice([0.0, reflective]))
+        p = [np.float32(c + rng.uniform(-1.2, 1.2, 3)).astype(np.float64) for _ in range(3)]
+        b.add_triangle(p[0], p[1], p[2], m)
+    return b.finish(2)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("seed,ns,nt,refl", [(1, 5, 0, 0.0), (2, 0, 40, 0.0), (3, 4, 60, 0.4), (4, 7, 200, 0.8),
+                                             (5, 1, 1, 0.5), (6, 0, 0, 0.0)])
+def test_seeded_scenes_match_oracle(hip, seed, ns, nt, refl, accel):
+    """Mixed sphere/triangle worlds with reflections: HIP canvas vs oracle canvas, same inputs."""
+    s = random_scene(seed, 120, 80, ns, nt, refl)
+    want, ost = O.render_f64(s)
+    assert O.probe().exact_zero_t == 0 and O.probe().list_overflow == 0
+    hip.upload(s)
+    got, st = hip.render_f64(accel=accel, count_rays=True)
+    assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+    ex, npx = assert_image_parity(quantise(got), quantise(want), f"seed {seed}")
+    assert ex == npx
+
+
+@pytest.mark.parametrize("n_ranks,band_rows", [(2, 4), (3, 5), (8, 8), (4, 1)])
+def test_row_bands_reassemble(hip, manifest, n_ranks, band_rows):
+    """N ranks' bands put back in place equal the 1-rank image byte for byte."""
+    e = manifest["cube_spheres_refl_96x64"]
+    hip.upload(scene_for(e))
+    full, _ = hip.render()
+    out = np.zeros_like(full)
+    rows_total = 0
+    for rank in range(n_ranks):
+        part, st = hip.render(n_ranks=n_ranks, band_rows=band_rows, rank=rank)
+        ys = R.rank_row_map(e["height"], band_rows, n_ranks, rank)
+        assert part.shape[0] == len(ys) == st.rows_rendered
+        out[ys] = part
+        rows_total += len(ys)
+    assert rows_total == e["height"]
+    assert np.array_equal(out, full)
+
+
+def test_device_output_path(hip, manifest):
+    """rt_hip_render_device into a torch tensor on the caller's stream equals the host path."""
+    import torch
+
+    e = manifest["spheres_96x64"]
+    hip.upload(scene_for(e))
+    want, _ = hip.render()
+    buf = torch.zeros((e["height"], e["width"], 3), dtype=torch.uint8, device="cuda:0")
+    p = R.make_params()
+    hip.render_device(buf.data_ptr(), p, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), want)
+
+
+def test_errors_are_returned_not_raised_by_abort(hip, manifest):
+    e = manifest["cube_96x64"]
+    hip.upload(scene_for(e))
+    with pytest.raises(R.RtError):
+        hip.render(max_depth=99)
+    with pytest.raises(R.RtError):
+        hip.render(n_ranks=2, band_rows=4, rank=2)
+    s = scene_for(e, bvh_leaf_size=0)
+    hip.upload(s)
+    with pytest.raises(R.RtError):
+        hip.render(accel=R._ffi.RT_ACCEL_BVH)
