@@ -185,6 +185,13 @@ int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank);
 /* Image row held at packed row `i` of rank `rank`'s buffer. */
 int rt_hip_rank_row_to_y(int i, int band_rows, int n_ranks, int rank);
 
+/* Timing helpers for callers that pipeline several renders: record a start
+ * (which == 0) or stop (which == 1) hipEvent on `stream` (NULL = the library's
+ * stream), then read the elapsed milliseconds (waits for the stop event).
+ * The reference times render() with clock() around the call (RayTracer.c:7236-7249). */
+int rt_hip_event_record(int which, void* stream);
+int rt_hip_event_elapsed_ms(double* ms_out);
+
 /* Release device memory, stream and events. */
 void rt_hip_shutdown(void);
 

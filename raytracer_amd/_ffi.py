@@ -176,6 +176,8 @@ def hip_lib():
         L.rt_hip_render_f64.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_rank_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_hip_rank_row_to_y.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rt_hip_event_record.argtypes = [C.c_int, C.c_void_p]
+        L.rt_hip_event_elapsed_ms.argtypes = [C.POINTER(C.c_double)]
         L.rt_hip_shutdown.restype = None
         L.rt_hip_strerror.argtypes = [C.c_int]
         L.rt_hip_strerror.restype = C.c_char_p
@@ -192,6 +194,8 @@ HIP_EXPORTS = [
     "rt_hip_render_f64",
     "rt_hip_rank_rows",
     "rt_hip_rank_row_to_y",
+    "rt_hip_event_record",
+    "rt_hip_event_elapsed_ms",
     "rt_hip_shutdown",
     "rt_hip_strerror",
     "rt_hip_last_error",

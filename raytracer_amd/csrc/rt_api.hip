@@ -25,7 +25,8 @@ struct Context {
   bool have_scene = false;
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
+  hipEvent_t tm0 = nullptr, tm1 = nullptr; /* caller-driven timer */
   DevScene scene{};
   bool reflective = false;
   void* d_spheres = nullptr;
@@ -181,6 +182,8 @@ int rt_hip_init(int device) {
   HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&g.ev0));
   HIP_TRY(hipEventCreate(&g.ev1));
+  HIP_TRY(hipEventCreate(&g.tm0));
+  HIP_TRY(hipEventCreate(&g.tm1));
   HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
   g.device = device;
   g.ready = true;
@@ -365,6 +368,24 @@ int rt_hip_render_f64(const rt_render_params* p, double* canvas_out, rt_stats* s
   return RT_OK;
 }
 
+int rt_hip_event_record(int which, void* stream) {
+  if (!g.ready) return RT_ERR_NOT_READY;
+  if (which != 0 && which != 1) return RT_ERR_INVALID;
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  HIP_TRY(hipEventRecord(which == 0 ? g.tm0 : g.tm1, s));
+  return RT_OK;
+}
+
+int rt_hip_event_elapsed_ms(double* ms_out) {
+  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!ms_out) return RT_ERR_INVALID;
+  HIP_TRY(hipEventSynchronize(g.tm1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g.tm0, g.tm1));
+  *ms_out = ms;
+  return RT_OK;
+}
+
 void rt_hip_shutdown(void) {
   if (!g.ready) return;
   (void)hipSetDevice(g.device);
@@ -375,6 +396,8 @@ void rt_hip_shutdown(void) {
   if (g.d_canvas) (void)hipFree(g.d_canvas);
   if (g.ev0) (void)hipEventDestroy(g.ev0);
   if (g.ev1) (void)hipEventDestroy(g.ev1);
+  if (g.tm0) (void)hipEventDestroy(g.tm0);
+  if (g.tm1) (void)hipEventDestroy(g.tm1);
   if (g.stream) (void)hipStreamDestroy(g.stream);
   g = Context{};
 }

@@ -74,6 +74,17 @@ class HipRenderer:
             "rt_hip_render_device",
         )
 
+    def timer_start(self, stream=None):
+        _check(self._L.rt_hip_event_record(0, C.c_void_p(stream or 0)), "rt_hip_event_record")
+
+    def timer_stop(self, stream=None):
+        _check(self._L.rt_hip_event_record(1, C.c_void_p(stream or 0)), "rt_hip_event_record")
+
+    def timer_ms(self):
+        ms = C.c_double()
+        _check(self._L.rt_hip_event_elapsed_ms(C.byref(ms)), "rt_hip_event_elapsed_ms")
+        return ms.value
+
     def shutdown(self):
         self._L.rt_hip_shutdown()
 
