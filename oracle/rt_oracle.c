@@ -497,6 +497,23 @@ int rto_prepare(const rt_scene* scene, const rto_ray* r, int order, double t, do
   return c.inside;
 }
 
+int rto_hit_list(const double* ts, int n) {
+  isect_list l;
+  list_init(&l);
+  for (int i = 0; i < n; ++i) list_add(&l, ts[i], i);
+  list_sort(&l);
+  const isect_t* h = list_hit(&l);
+  return h ? (int)h->id : -1;
+}
+
+int rto_list_capacity(int attempts) {
+  isect_list l;
+  list_init(&l);
+  int ok = 0;
+  for (int i = 0; i < attempts; ++i) ok += list_add(&l, 1.0, i);
+  return ok;
+}
+
 int rto_write_ppm(const char* path, const uint8_t* rgb, int width, int height) { /* lines 1333-1348 */
   FILE* fp = fopen(path, "w");
   if (!fp) return RT_ERR_INVALID;

@@ -60,6 +60,12 @@ void rto_color_at(const rt_scene* scene, const rto_ray* r, int remaining, double
 /* prepare_computations: out = point[3], eyev[3], normalv[3], over_point[3], reflectv[3], inside */
 int rto_prepare(const rt_scene* scene, const rto_ray* r, int order, double t, double out[16]); /* RayTracer.c:1360 */
 
+/* intersections list alone: append ts[0..n) in order, sort, hit(); returns the insertion index of the hit or -1
+ * (RayTracer.c:159, 139, 143) */
+int rto_hit_list(const double* ts, int n);
+/* how many of `attempts` appends of t = 1.0 the 100-slot list accepts (RayTracer.c:161-165) */
+int rto_list_capacity(int attempts);
+
 /* P3 text exactly as write_canvas_to_file emits it (RayTracer.c:1333-1348) */
 int rto_write_ppm(const char* path, const uint8_t* rgb, int width, int height);
 

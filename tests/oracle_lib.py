@@ -49,6 +49,8 @@ def lib():
         L.rto_color_at.argtypes = [SP, C.POINTER(Ray), C.c_int, _dp]
         L.rto_color_at.restype = None
         L.rto_prepare.argtypes = [SP, C.POINTER(Ray), C.c_int, C.c_double, _dp]
+        L.rto_hit_list.argtypes = [_dp, C.c_int]
+        L.rto_list_capacity.argtypes = [C.c_int]
         L.rto_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib

@@ -1,0 +1,67 @@
+"""N > 1 path on CPU: two gloo ranks each produce their round-robin row bands, one gather puts the image
+together on rank 0, and it must equal the 1-rank image byte for byte.  The per-rank renderer here is the CPU
+oracle (this is a test of the partition + gather plumbing, not of the kernels)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, band_rows, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib as O
+    import raytracer_amd as R
+    from raytracer_amd.dist import BandGather
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 61, 45
+    scene = R.stock_scene("cube_spheres", W, H, tri_reflective=0.3, sph_reflective=0.3)
+    bg = BandGather(H, W, band_rows, world, rank, torch.device("cpu"))
+    part, st = O.render_rgb(scene, n_ranks=world, band_rows=band_rows, rank=rank)
+    assert part.shape[0] == bg.n_local
+    bg.local[: bg.n_local] = torch.from_numpy(part)
+    rays = torch.tensor([st.rays], dtype=torch.int64)
+    dist.all_reduce(rays)
+    img = bg.gather()
+    if rank == 0:
+        full, fst = O.render_rgb(scene)
+        assert rays.item() == fst.rays
+        np.save(out_path, np.stack([img.numpy(), full]))
+    else:
+        assert img is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,band_rows", [(2, 4), (3, 1)])
+def test_two_rank_bands_gather_to_the_one_rank_image(tmp_path, world, band_rows):
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), band_rows, out), nprocs=world, join=True)
+    got, want = np.load(out)
+    assert np.array_equal(got, want)
+
+
+def test_band_helpers():
+    from raytracer_amd.dist import default_band_rows, rank_rows
+
+    assert default_band_rows(1080, 8) == 16
+    assert default_band_rows(20, 8) >= 1
+    ys = [rank_rows(50, 4, 3, r) for r in range(3)]
+    assert sorted(np.concatenate(ys).tolist()) == list(range(50))
