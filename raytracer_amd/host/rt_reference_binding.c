@@ -1,0 +1,71 @@
+/*
+ * rt_reference_binding.c - the binding a maintainer of the reference adds to
+ * RayTracer.c: render() on the MI355X instead of the CPU loop.
+ *
+ * This file is written against the reference's OWN types (camera, world,
+ * shape, material, tuple, Mat4x4: RayTracer/RayTracer.c:45-96) and is meant to
+ * be compiled inside the reference's translation unit, after its definitions:
+ *
+ *     #include "rt_reference_binding.c"      // at the end of RayTracer.c
+ *     ... and the body of render() (RayTracer.c:1574) becomes
+ *     void render(camera* c, world* w) { rt_render_hip(c, w); }
+ *
+ * It walks world->objects once (the list the reference walks per ray,
+ * RayTracer.c:1047-1051), hands transforms / vertices / materials to the scene
+ * builder of rt_scene.h, renders, and stores the colours where write_pixel()
+ * (RayTracer.c:257) would have put them, so write_canvas_to_file() emits the
+ * same canvas.ppm.
+ */
+#include "rt_hip.h"
+#include "rt_scene.h"
+
+static rt_material rt_binding_material(const material* m) {
+  rt_material o;
+  o.color[0] = m->color.x; o.color[1] = m->color.y; o.color[2] = m->color.z;
+  o.ambient = m->ambient; o.diffuse = m->diffuse; o.specular = m->specular;
+  o.shininess = m->shininess; o.reflective = m->reflective;
+  return o;
+}
+
+/* returns RT_OK or a negative rt_status; RT_ERR_UNSUPPORTED means the world holds something outside the
+ * accelerated path (plane, cube, cylinder, pattern, transparency) and the caller should keep its CPU loop */
+int rt_render_hip(camera* c, world* w) {
+  if ((int)c->hsize != HORIZONTAL_SIZE || (int)c->vsize != VERTICAL_SIZE) return RT_ERR_UNSUPPORTED; /* canvas[][] is fixed */
+  rt_scene_builder* b = rt_scene_create();
+  if (!b) return RT_ERR_INVALID;
+  int rc = rt_scene_set_camera_view(b, (int)c->hsize, (int)c->vsize, c->field_of_view, &c->view_transform[0][0]);
+  const double lp[3] = {w->lights->position.x, w->lights->position.y, w->lights->position.z};
+  const double li[3] = {w->lights->intensity.x, w->lights->intensity.y, w->lights->intensity.z};
+  if (rc == RT_OK) rc = rt_scene_set_light(b, lp, li);
+  for (shape* sp = w->objects; sp && rc >= 0; sp = sp->next) {
+    if (sp->material.has_pattern || sp->material.transparency != 0.0) { rc = RT_ERR_UNSUPPORTED; break; }
+    rt_material m = rt_binding_material(&sp->material);
+    if (sp->type == SPHERE) {
+      rc = rt_scene_add_sphere(b, &sp->transform[0][0], &m);
+    } else if (sp->type == TRIANGLE) {
+      const double p1[3] = {sp->p1.x, sp->p1.y, sp->p1.z}, p2[3] = {sp->p2.x, sp->p2.y, sp->p2.z},
+                   p3[3] = {sp->p3.x, sp->p3.y, sp->p3.z};
+      rc = rt_scene_add_triangle(b, p1, p2, p3, &m);
+    } else {
+      rc = RT_ERR_UNSUPPORTED;
+    }
+  }
+  rt_scene s;
+  if (rc >= 0) rc = rt_scene_finish(b, 4, &s);
+  if (rc == RT_OK) rc = rt_hip_init(0);
+  if (rc == RT_OK) rc = rt_hip_upload_scene(&s);
+  if (rc == RT_OK) {
+    static double colours[HORIZONTAL_SIZE * VERTICAL_SIZE * 3];
+    rt_render_params p = {RECURSION_DEPTH, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, 0};
+    rc = rt_hip_render_f64(&p, colours, NULL);
+    if (rc == RT_OK)
+      for (int y = 0; y < VERTICAL_SIZE; ++y)
+        for (int x = 0; x < HORIZONTAL_SIZE; ++x) {
+          const double* px = colours + ((size_t)y * HORIZONTAL_SIZE + x) * 3;
+          tuple col = {px[0], px[1], px[2], 1.0};
+          write_pixel(x, y, col);
+        }
+  }
+  rt_scene_destroy(b);
+  return rc;
+}
