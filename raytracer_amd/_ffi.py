@@ -159,7 +159,8 @@ def hip_lib():
     """librt_hip.so: the C-ABI over the gfx950 kernels.  No fallback: missing library is an error."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "librt_hip.so")
+        tag = os.environ.get("RT_HIP_LIB")  # development: an alternative build of the same library
+        path = os.path.join(LIB_DIR, f"librt_hip_{tag}.so" if tag else "librt_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C raytracer_amd` (or __graft_entry__.build())")
         # PyTorch ships its own libamdhip64.so.7.  A process must hold ONE HIP runtime: load torch's first so

@@ -24,6 +24,9 @@ struct Context {
   bool ready = false;
   bool have_scene = false;
   int device = -1;
+  int n_cu = 256;
+  int tiles_per_block = 1;
+  bool use_lds = true;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
   hipEvent_t tm0 = nullptr, tm1 = nullptr; /* caller-driven timer */
@@ -34,6 +37,9 @@ struct Context {
   void* d_normals = nullptr;
   void* d_materials = nullptr;
   void* d_bvh = nullptr;
+  DevScene* d_scene = nullptr; /* device copy of `scene` */
+  void* d_tri_primary = nullptr;
+  void* d_sph_primary = nullptr;
   unsigned long long* d_counters = nullptr;
   unsigned char* d_rgb = nullptr;  /* library-owned output for rt_hip_render */
   size_t d_rgb_bytes = 0;
@@ -60,7 +66,9 @@ void free_scene() {
   if (g.d_normals) (void)hipFree(g.d_normals);
   if (g.d_materials) (void)hipFree(g.d_materials);
   if (g.d_bvh) (void)hipFree(g.d_bvh);
-  g.d_spheres = g.d_tris = g.d_normals = g.d_materials = g.d_bvh = nullptr;
+  if (g.d_tri_primary) (void)hipFree(g.d_tri_primary);
+  if (g.d_sph_primary) (void)hipFree(g.d_sph_primary);
+  g.d_spheres = g.d_tris = g.d_normals = g.d_materials = g.d_bvh = g.d_tri_primary = g.d_sph_primary = nullptr;
   g.have_scene = false;
 }
 
@@ -79,29 +87,56 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
   return 1 + (l > r ? l : r);
 }
 
-template <bool COUNT, bool BVH, bool REFLECT>
-void launch_f64(bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
-  if (f64)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, true>), grid, dim3(RT_TILE_W * RT_TILE_H), 0, s, g.scene, a,
-                       rgb, canvas, g.d_counters);
+/* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
+ * workgroups per CU */
+constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
+constexpr int kMaxLdsBvhNodes = 1536; /* 1536 * 32 B = 48 KiB */
+
+template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
+void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+                  double* canvas) {
+  const dim3 block(RT_TILE_W * RT_TILE_H);
+  if (stage == 0)
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0>), grid, block, 0, s, g.d_scene, a, rgb, canvas,
+                       g.d_counters);
+  else if (BVH)
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0>), grid, block, lds, s, g.d_scene, a, rgb,
+                       canvas, g.d_counters);
   else
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, false>), grid, dim3(RT_TILE_W * RT_TILE_H), 0, s, g.scene,
-                       a, rgb, canvas, g.d_counters);
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1>), grid, block, lds, s, g.d_scene, a, rgb,
+                       canvas, g.d_counters);
+}
+template <bool COUNT, bool BVH, bool REFLECT>
+void launch_f64(bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+                double* canvas) {
+  if (f64) launch_stage<COUNT, BVH, REFLECT, true>(stage, lds, grid, s, a, rgb, canvas);
+  else launch_stage<COUNT, BVH, REFLECT, false>(stage, lds, grid, s, a, rgb, canvas);
 }
 template <bool COUNT, bool BVH>
-void launch_refl(bool reflect, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
-                 double* canvas) {
-  if (reflect) launch_f64<COUNT, BVH, true>(f64, grid, s, a, rgb, canvas);
-  else launch_f64<COUNT, BVH, false>(f64, grid, s, a, rgb, canvas);
+void launch_refl(bool reflect, bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a,
+                 unsigned char* rgb, double* canvas) {
+  if (reflect) launch_f64<COUNT, BVH, true>(f64, stage, lds, grid, s, a, rgb, canvas);
+  else launch_f64<COUNT, BVH, false>(f64, stage, lds, grid, s, a, rgb, canvas);
 }
 void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a,
             unsigned char* rgb, double* canvas) {
+  int stage = 0;
+  size_t lds = 0;
+  if (g.use_lds) {
+    if (!bvh && g.scene.n_tris > 0 && g.scene.n_tris <= kMaxLdsTris) {
+      stage = 1;
+      lds = (size_t)g.scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
+    } else if (bvh && g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
+      stage = 2;
+      lds = (size_t)g.scene.n_bvh_nodes * sizeof(rt_bvh_node);
+    }
+  }
   if (count) {
-    if (bvh) launch_refl<true, true>(reflect, f64, grid, s, a, rgb, canvas);
-    else launch_refl<true, false>(reflect, f64, grid, s, a, rgb, canvas);
+    if (bvh) launch_refl<true, true>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
+    else launch_refl<true, false>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
   } else {
-    if (bvh) launch_refl<false, true>(reflect, f64, grid, s, a, rgb, canvas);
-    else launch_refl<false, false>(reflect, f64, grid, s, a, rgb, canvas);
+    if (bvh) launch_refl<false, true>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
+    else launch_refl<false, false>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
   }
 }
 
@@ -109,7 +144,8 @@ int check_params(const rt_render_params* p) {
   if (!p) return RT_ERR_INVALID;
   if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
   if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH) return RT_ERR_TOO_LARGE;
-  if (p->spp_grid < 1 || p->spp_grid > 64) return RT_ERR_INVALID;
+  if (p->spp_grid < 1) return RT_ERR_INVALID;
+  if (p->spp_grid > RT_MAX_SPP_GRID) return RT_ERR_TOO_LARGE;
   if (p->n_ranks < 1 || p->rank < 0 || p->rank >= p->n_ranks) return RT_ERR_INVALID;
   if (p->n_ranks > 1 && p->band_rows < 1) return RT_ERR_INVALID;
   if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH) return RT_ERR_INVALID;
@@ -128,6 +164,8 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   a.n_ranks = p->n_ranks;
   a.rank = p->rank;
   a.rows = rows;
+  a.ablate = p->reserved;
+  for (int i = 0; i < RT_MAX_SPP_GRID; ++i) a.sample_off[i] = (i + 0.5) / a.spp_grid; /* ref_harness / oracle: (i + 0.5) / G */
   bool bvh = g.scene.n_bvh_nodes > 0 && g.scene.n_tris > 0;
   if (p->accel == RT_ACCEL_BRUTE) bvh = false;
   if (p->accel == RT_ACCEL_AUTO && g.scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
@@ -136,7 +174,9 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
     if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 5 * sizeof(unsigned long long), s));
-    dim3 grid((unsigned)((W + RT_TILE_W - 1) / RT_TILE_W), (unsigned)((rows + RT_TILE_H - 1) / RT_TILE_H));
+    const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
+    a.tiles_per_block = g.tiles_per_block;
+    dim3 grid((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block));
     if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
     launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
@@ -185,6 +225,14 @@ int rt_hip_init(int device) {
   HIP_TRY(hipEventCreate(&g.tm0));
   HIP_TRY(hipEventCreate(&g.tm1));
   HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("RT_HIP_LDS")) g.use_lds = atoi(e) != 0; /* tuning knob: 0 = read primitives from global memory */
+  if (const char* e = getenv("RT_HIP_TILES_PER_BLOCK")) { /* tuning knob */
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) g.tiles_per_block = v;
+  }
   g.device = device;
   g.ready = true;
   return RT_OK;
@@ -261,7 +309,49 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     ht[k].material = sc->tri_material[i];
     ht[k].order = sc->tri_order[i];
   }
+  /* camera origin = inv_view * point(0,0,0), mat4x4_mul_tuple order (RayTracer.c:419, 1563) */
+  double org[3];
+  for (int r = 0; r < 3; ++r) {
+    const double* m = sc->camera.inv_view + 4 * r;
+    org[r] = ((0.0 * m[0] + 0.0 * m[1]) + 0.0 * m[2]) + 1.0 * m[3];
+  }
+  /* origin-only terms of the two intersection routines, in the reference's operation order
+   * (host code is built without FMA contraction, like the reference binary) */
+  std::vector<DevTriPrimary> htp((size_t)(nt > 0 ? nt : 1));
+  double amax = 1.0, blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < nt; ++k) {
+    const DevTri& t = ht[k];
+    double s[3], q[3];
+    for (int c = 0; c < 3; ++c) s[c] = org[c] - t.p1[c];                 /* tuple_sub, :951 */
+    q[0] = s[1] * t.e1[2] - s[2] * t.e1[1];                               /* tuple_cross(s, e1), :957 */
+    q[1] = s[2] * t.e1[0] - s[0] * t.e1[2];
+    q[2] = s[0] * t.e1[1] - s[1] * t.e1[0];
+    for (int c = 0; c < 3; ++c) { htp[k].s[c] = s[c]; htp[k].q[c] = q[c]; }
+    htp[k].tq = (t.e2[0] * q[0] + t.e2[1] * q[1]) + t.e2[2] * q[2];       /* tuple_dot(e2, q), :963 */
+    htp[k].pad = 0.0;
+    for (int c = 0; c < 3; ++c) {
+      const double v[3] = {t.p1[c], t.p1[c] + t.e1[c], t.p1[c] + t.e2[c]};
+      for (double x : v) {
+        if (x < blo[c]) blo[c] = x;
+        if (x > bhi[c]) bhi[c] = x;
+        if (std::fabs(x) > amax) amax = std::fabs(x);
+      }
+    }
+  }
+  for (int c = 0; c < 3; ++c) if (std::fabs(org[c]) > amax) amax = std::fabs(org[c]);
+  amax = std::fmax(amax, std::fmax(std::fabs(sc->light.position[0]),
+                                   std::fmax(std::fabs(sc->light.position[1]), std::fabs(sc->light.position[2]))));
+  std::vector<DevSpherePrimary> hsp((size_t)(ns > 0 ? ns : 1));
+  for (int i = 0; i < ns; ++i) {
+    const double* m = hs[i].inv;
+    double o[3];
+    for (int r = 0; r < 3; ++r) o[r] = ((org[0] * m[4 * r] + org[1] * m[4 * r + 1]) + org[2] * m[4 * r + 2]) + m[4 * r + 3];
+    for (int c = 0; c < 3; ++c) hsp[i].o[c] = o[c];
+    hsp[i].c = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) - 1.0;          /* tuple_dot - 1.0, :927 */
+  }
   int rc;
+  if ((rc = upload(&g.d_tri_primary, htp.data(), sizeof(DevTriPrimary) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&g.d_sph_primary, hsp.data(), sizeof(DevSpherePrimary) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&g.d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&g.d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&g.d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
@@ -275,11 +365,16 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   d.half_width = sc->camera.half_width;
   d.half_height = sc->camera.half_height;
   memcpy(d.inv_view, sc->camera.inv_view, 12 * sizeof(double));
-  /* inv_view * point(0,0,0), mat4x4_mul_tuple order (RayTracer.c:419, 1563) */
-  for (int r = 0; r < 3; ++r) {
-    const double* m = sc->camera.inv_view + 4 * r;
-    d.origin[r] = ((0.0 * m[0] + 0.0 * m[1]) + 0.0 * m[2]) + 1.0 * m[3];
+  for (int r = 0; r < 3; ++r) d.origin[r] = org[r];
+  /* bounds of all triangles for the single-precision early-out: padded by ~500 float ulps of the largest
+   * coordinate in play, far more than single-precision rounding of origin, direction and slab products */
+  const double pad = 3e-5 * amax;
+  for (int c = 0; c < 3; ++c) {
+    d.box_lo[c] = nt ? std::nextafterf((float)(blo[c] - pad), -INFINITY) : 0.f;
+    d.box_hi[c] = nt ? std::nextafterf((float)(bhi[c] + pad), INFINITY) : 0.f;
   }
+  d.tri_primary = (const DevTriPrimary*)g.d_tri_primary;
+  d.sph_primary = (const DevSpherePrimary*)g.d_sph_primary;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
   memcpy(d.light_int, sc->light.intensity, sizeof d.light_int);
   d.hsize = sc->camera.hsize;
@@ -296,6 +391,8 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   g.reflective = false;
   for (int i = 0; i < sc->n_materials; ++i)
     if (!(std::fabs(sc->materials[i].reflective - 0.0) < RT_EPSILON)) g.reflective = true;
+  if (!g.d_scene) HIP_TRY(hipMalloc((void**)&g.d_scene, sizeof(DevScene)));
+  HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
   g.have_scene = true;
   return RT_OK;
 }
@@ -392,6 +489,7 @@ void rt_hip_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   free_scene();
   if (g.d_counters) (void)hipFree(g.d_counters);
+  if (g.d_scene) (void)hipFree(g.d_scene);
   if (g.d_rgb) (void)hipFree(g.d_rgb);
   if (g.d_canvas) (void)hipFree(g.d_canvas);
   if (g.ev0) (void)hipEventDestroy(g.ev0);

@@ -35,9 +35,30 @@ __device__ __forceinline__ d3 cross3(d3 a, d3 b) {                              
   return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ double mag3(d3 a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); } /* :335 */
-__device__ __forceinline__ d3 normalize3(d3 a) {                                                   /* :344 */
-  const double m = mag3(a);
+
+/* Three correctly rounded quotients by one divisor.  a / m in IEEE double is what the compiler's own
+ * expansion computes as: y = 1/m refined by two Newton steps from v_rcp_f64, q = a * y,
+ * r = fma(-m, q, a), result = fma(r, y, q) - wrapped in v_div_scale / v_div_fixup for operands near the
+ * ends of the exponent range.  Here y is formed once and shared, and the wrapping is replaced by a range
+ * check that sends anything unusual to the plain '/' (same value, slower).  Every result is the IEEE
+ * quotient, so tuple_normalize's three divisions (:346) keep their bits. */
+__device__ __forceinline__ bool div_fast_ok(double v) {
+  const double a = fabs(v);
+  return a == 0.0 || (a > 1e-100 && a < 1e100);
+}
+__device__ __forceinline__ d3 div3_by(d3 a, double m) {
+  if (div_fast_ok(a.x) && div_fast_ok(a.y) && div_fast_ok(a.z) && m > 1e-100 && m < 1e100) {
+    double y = __builtin_amdgcn_rcp(m);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    const double qx = a.x * y, qy = a.y * y, qz = a.z * y;
+    return mk3(__builtin_fma(__builtin_fma(-m, qx, a.x), y, qx), __builtin_fma(__builtin_fma(-m, qy, a.y), y, qy),
+               __builtin_fma(__builtin_fma(-m, qz, a.z), y, qz));
+  }
   return mk3(a.x / m, a.y / m, a.z / m);
+}
+__device__ __forceinline__ d3 normalize3(d3 a) {                                                   /* :344 */
+  return div3_by(a, mag3(a));
 }
 __device__ __forceinline__ d3 reflect3(d3 in, d3 n) {                                              /* :1065 */
   const d3 two_n = scale3(n, 2.0);

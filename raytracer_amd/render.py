@@ -25,8 +25,9 @@ def _check(rc, what):
         raise RtError(what, rc)
 
 
-def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0):
-    return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, 0)
+def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0,
+                reserved=0):
+    return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, reserved)
 
 
 class HipRenderer:
