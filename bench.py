@@ -34,9 +34,47 @@ from raytracer_amd.dist import BandGather, default_band_rows  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "cube"  # render_some_triangles + the teapot.h mesh (12 triangles), RayTracer.c:6727
-FLOP_PER_TRI_TEST = 45  # full Moeller-Trumbore path, RayTracer.c:943-966
-FLOP_PER_SPHERE_TEST = 63
+# algorithmic FLOPs per unit of work (the figures the survey fixed for this path)
+FLOP_PER_TRI_TEST = 45      # full Moeller-Trumbore path, RayTracer.c:943-966
+FLOP_PER_SPHERE_TEST = 63   # two affine mat-vec + quadratic, RayTracer.c:898-940
+FLOP_PER_BOX_TEST = 18      # slab test (BVH node or mesh bounds)
+FLOP_PER_PRIMARY_RAY = 30   # ray_for_pixel, RayTracer.c:1535
+FLOP_PER_SHADED_HIT = 80    # prepare_computations + lighting (+ 1 pow), RayTracer.c:1360, 1273
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak
+
+
+def algorithmic_flops(st):
+    """FLOPs of the work the kernel actually did in one launch, from its own counters (counting build)."""
+    tri_tests = st.prim_tests - st.sphere_tests
+    return (st.rays_primary * FLOP_PER_PRIMARY_RAY + st.rays_shadow * FLOP_PER_SHADED_HIT
+            + tri_tests * FLOP_PER_TRI_TEST + st.sphere_tests * FLOP_PER_SPHERE_TEST + st.node_tests * FLOP_PER_BOX_TEST)
+
+
+def side_measurements(hip, dev, steps=100):
+    """Context for the headline: the other BASELINE scenes at 1920x1080 on this GPU, kernel time from HIP events."""
+    out = {}
+    buf = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
+    for name, scene, tr, accel in (("spheres_1080p", "spheres", 0.0, R._ffi.RT_ACCEL_AUTO),
+                                   ("lighthouse_1080p_bvh", "lighthouse", 0.0, R._ffi.RT_ACCEL_BVH),
+                                   ("lighthouse_1080p_exhaustive", "lighthouse", 0.0, R._ffi.RT_ACCEL_BRUTE),
+                                   ("lighthouse_1080p_reflective_bvh", "lighthouse", 0.3, R._ffi.RT_ACCEL_BVH)):
+        hip.upload(R.stock_scene(scene, WIDTH, HEIGHT, tr))
+        st = R._ffi.Stats()
+        hip.render_device(buf.data_ptr(), R.make_params(accel=accel, count_rays=True), stats=st)
+        p = R.make_params(accel=accel)
+        n = steps if accel != R._ffi.RT_ACCEL_BRUTE else 10
+        for _ in range(3):
+            hip.render_device(buf.data_ptr(), p)
+        hip.timer_start()
+        for _ in range(n):
+            hip.render_device(buf.data_ptr(), p)
+        hip.timer_stop()
+        ms = hip.timer_ms() / n
+        fl = algorithmic_flops(st)
+        out[name] = {"rays": st.rays, "kernel_ms": round(ms, 5), "mrays_s": round(st.rays / ms / 1e3, 1),
+                     "tflops_algorithmic": round(fl / ms / 1e9, 3), "tri_tests": st.prim_tests - st.sphere_tests,
+                     "sphere_tests": st.sphere_tests, "box_tests": st.node_tests}
+    return out
 
 
 def cpu_baseline(rays_expected):
@@ -69,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the other-scenes context measurements")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,17 +117,24 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit(f"--gpus {a.gpus}: launch with python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box: RT_BENCH_REHEARSE=1 puts every rank on device 0 and gathers through gloo
+    # (RCCL refuses two ranks on one device).  The driver's real runs use one GPU per rank and RCCL.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    hip = R.HipRenderer(local_rank)
+    hip = R.HipRenderer(device_index)
     scene = R.stock_scene(SCENE, WIDTH, HEIGHT)
     hip.upload(scene)
     band_rows = default_band_rows(HEIGHT, world)
-    bg = BandGather(HEIGHT, WIDTH, band_rows, world, rank, dev)
+    bg = BandGather(HEIGHT, WIDTH, band_rows, world, rank, dev, slots=2)
     p = R.make_params(max_depth=5, spp_grid=1, accel=R._ffi.RT_ACCEL_AUTO, band_rows=band_rows, n_ranks=world, rank=rank)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -96,18 +142,35 @@ def main():
     pc = R.make_params(max_depth=5, count_rays=True, band_rows=band_rows, n_ranks=world, rank=rank)
     st = R._ffi.Stats()
     hip.render_device(bg.local.data_ptr(), pc, stream=stream, stats=st)
-    my_rays = torch.tensor([st.rays, st.prim_tests], dtype=torch.float64, device=dev)
+    my_rays = torch.tensor([st.rays, st.prim_tests], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(my_rays)
     total_rays, _ = [int(x) for x in my_rays.tolist()]
     accel_used = "bvh" if st.accel_used == R._ffi.RT_ACCEL_BVH else "brute"
 
+    # Two buffer slots: frame i renders while the gather of frame i - 1 is in flight; a slot is reused only
+    # after its previous gather has been waited for (stream-ordered), and every frame's image is assembled.
+    pending = [None, None]
+    frame = [0]
+
     def step():
-        hip.render_device(bg.local.data_ptr(), p, stream=stream)
-        return bg.gather()
+        k = frame[0] % 2
+        frame[0] += 1
+        if pending[k] is not None:
+            bg.finish(pending[k], k)
+        hip.render_device(bg.locals[k].data_ptr(), p, stream=stream)
+        if world > 1:
+            pending[k] = bg.gather_async(k)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                bg.finish(pending[k], k)
+                pending[k] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -115,21 +178,29 @@ def main():
     hip.timer_start(stream)
     for _ in range(a.steps):
         step()
+    drain()
     hip.timer_stop(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     ev_ms = hip.timer_ms()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        # the kernel alone (no gather between launches), for the roofline line
+        hip.timer_start(stream)
+        for _ in range(50):
+            hip.render_device(bg.locals[0].data_ptr(), p, stream=stream)
+        hip.timer_stop(stream)
+        ev_ms = hip.timer_ms() / 50 * a.steps
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     if rank == 0:
-        n_prim_flops = scene.n_tris * FLOP_PER_TRI_TEST + scene.n_spheres * FLOP_PER_SPHERE_TEST
-        # per launch of THIS rank's kernel: its rays x every primitive (brute-force definition)
-        flops_per_launch = st.rays * n_prim_flops
+        # per launch of THIS rank's kernel, from the counting build of the same kernel on the same rows
+        flops_per_launch = algorithmic_flops(st)
+        exhaustive_flops = st.rays * (scene.n_tris * FLOP_PER_TRI_TEST + scene.n_spheres * FLOP_PER_SPHERE_TEST)
         kernel_ms = ev_ms / a.steps  # HIP events on the launch stream around the K launches
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         line = {
@@ -153,11 +224,17 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
                          "kernel": "rt_trace_kernel", "kernel_ms": round(kernel_ms, 5),
                          "flops_per_launch": flops_per_launch,
-                         "note": "algorithmic FLOPs = rays x 12 triangles x 45; arithmetic is FP64 without FMA "
-                                 "(parity with the reference), priced against the FP32 vector peak"},
+                         "counters": {"tri_tests": st.prim_tests - st.sphere_tests, "sphere_tests": st.sphere_tests,
+                                      "box_tests": st.node_tests, "primary": st.rays_primary, "shaded": st.rays_shadow},
+                         "exhaustive_equivalent_tflops": round(exhaustive_flops / (kernel_ms * 1e-3) / 1e12, 3),
+                         "note": "FLOPs = 30/primary ray + 80/shaded hit + 45/triangle test + 63/sphere test + 18/box test "
+                                 "actually executed (counting build of the same kernel); Arithmetic is FP64 without FMA (parity), priced against the FP32 "
+                                 "vector peak; exhaustive_equivalent = rays x 12 triangles x 45 over the same time"},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total_rays)
+        if world == 1 and not a.no_side:
+            line["other_scenes_1080p"] = side_measurements(hip, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

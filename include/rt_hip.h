@@ -145,8 +145,9 @@ typedef struct rt_stats {
   uint64_t rays_primary;    /* ray_for_pixel calls                               */
   uint64_t rays_shadow;     /* is_shadowed calls (one per shaded hit)            */
   uint64_t rays_secondary;  /* reflected rays spawned                            */
-  uint64_t prim_tests;      /* ray-primitive tests executed                      */
-  uint64_t node_tests;      /* ray-box tests executed (BVH only)                 */
+  uint64_t prim_tests;      /* ray-primitive tests executed (triangles + spheres) */
+  uint64_t node_tests;      /* ray-box tests executed (BVH nodes, mesh bounds)   */
+  uint64_t sphere_tests;    /* the ray-sphere part of prim_tests                 */
   double kernel_ms;         /* hipEvent time of the trace kernel, this call      */
   int32_t rows_rendered;    /* rows this rank produced                           */
   int32_t accel_used;       /* RT_ACCEL_BRUTE or RT_ACCEL_BVH                    */

@@ -97,6 +97,7 @@ class Stats(C.Structure):
         ("rays_secondary", C.c_uint64),
         ("prim_tests", C.c_uint64),
         ("node_tests", C.c_uint64),
+        ("sphere_tests", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("rows_rendered", C.c_int32),
         ("accel_used", C.c_int32),

@@ -173,7 +173,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   const bool reflect = g.reflective && p->max_depth >= 1;
   if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
-    if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 5 * sizeof(unsigned long long), s));
+    if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     a.tiles_per_block = g.tiles_per_block;
     dim3 grid((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block));
@@ -191,7 +191,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
       HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
       stats->kernel_ms = ms;
       if (count) {
-        unsigned long long c[5];
+        unsigned long long c[6];
         HIP_TRY(hipMemcpyAsync(c, g.d_counters, sizeof c, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         stats->rays_primary = c[0];
@@ -199,6 +199,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
         stats->rays_secondary = c[2];
         stats->prim_tests = c[3];
         stats->node_tests = c[4];
+        stats->sphere_tests = c[5];
       }
     }
   }

@@ -26,32 +26,58 @@ def default_band_rows(height, n_ranks):
 
 
 class BandGather:
-    """Buffers and index maps for gathering every rank's packed rows into the full image on rank 0."""
+    """Buffers and index maps for gathering every rank's packed rows into the full image on rank 0.
 
-    def __init__(self, height, width, band_rows, world_size, rank, device):
+    `slots` > 1 gives that many independent (local, gathered) buffer pairs so that a caller can render frame
+    i + 1 into one slot while the gather of frame i is still in flight on the communicator's stream.
+    """
+
+    def __init__(self, height, width, band_rows, world_size, rank, device, slots=1):
         self.height, self.width = height, width
         self.band_rows, self.world_size, self.rank = band_rows, world_size, rank
         self.rows = [rank_rows(height, band_rows, world_size, r) for r in range(world_size)]
         self.max_rows = max(len(r) for r in self.rows)
-        self.local = torch.zeros((self.max_rows, width, 3), dtype=torch.uint8, device=device)
         self.n_local = len(self.rows[rank])
-        self.gathered = None
+        self.slots = slots
+        self.locals = [torch.zeros((self.max_rows, width, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.local = self.locals[0]
+        self.gathereds = [None] * slots
         self.perm = None
+        # gloo moves host memory: device buffers are staged through the host (CPU tests, one-GPU rehearsals)
+        self.via_host = (world_size > 1 and torch.device(device).type == "cuda" and dist.is_initialized()
+                         and dist.get_backend() == "gloo")
         if rank == 0:
-            self.gathered = torch.zeros((world_size, self.max_rows, width, 3), dtype=torch.uint8, device=device)
+            self.gathereds = [torch.zeros((world_size, self.max_rows, width, 3), dtype=torch.uint8,
+                                          device="cpu" if self.via_host else device) for _ in range(slots)]
             # image row y comes from packed slot perm[y] of the flattened [world_size * max_rows] rows
             perm = np.empty(height, dtype=np.int64)
             for r, ys in enumerate(self.rows):
                 perm[ys] = r * self.max_rows + np.arange(len(ys))
             self.perm = torch.from_numpy(perm).to(device)
+        self.gathered = self.gathereds[0]
 
-    def gather(self):
-        """Collective: returns the full [height, width, 3] image on rank 0, None elsewhere."""
+    def gather_async(self, slot=0):
+        """Start the gather of slot `slot`; returns a handle for finish() (None when there is nothing to wait for)."""
         if self.world_size == 1:
-            return self.local[: self.n_local]
+            return None
+        local = self.locals[slot].cpu() if self.via_host else self.locals[slot]
         if self.rank == 0:
-            dist.gather(self.local, list(self.gathered.unbind(0)), dst=0)
-            flat = self.gathered.view(self.world_size * self.max_rows, self.width, 3)
-            return flat.index_select(0, self.perm)
-        dist.gather(self.local, None, dst=0)
-        return None
+            return dist.gather(local, list(self.gathereds[slot].unbind(0)), dst=0, async_op=True)
+        return dist.gather(local, None, dst=0, async_op=True)
+
+    def finish(self, handle, slot=0):
+        """Wait for a gather (stream-ordered on GPUs) and return the full image on rank 0, None elsewhere."""
+        if self.world_size == 1:
+            return self.locals[slot][: self.n_local]
+        if handle is not None:
+            handle.wait()
+        if self.rank != 0:
+            return None
+        flat = self.gathereds[slot].view(self.world_size * self.max_rows, self.width, 3)
+        if self.via_host:
+            flat = flat.to(self.perm.device)
+        return flat.index_select(0, self.perm)
+
+    def gather(self, slot=0):
+        """Collective: returns the full [height, width, 3] image on rank 0, None elsewhere."""
+        return self.finish(self.gather_async(slot), slot)
