@@ -92,25 +92,36 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
 constexpr int kMaxLdsBvhNodes = 1536; /* 1536 * 32 B = 48 KiB */
 
-template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
+template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT, int KIND>
 void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
                   double* canvas) {
   const dim3 block(RT_TILE_W * RT_TILE_H);
   if (stage == 0)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0>), grid, block, 0, s, g.d_scene, a, rgb, canvas,
-                       g.d_counters);
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, a, rgb,
+                       canvas, g.d_counters);
   else if (BVH)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0>), grid, block, lds, s, g.d_scene, a, rgb,
-                       canvas, g.d_counters);
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
+                       a, rgb, canvas, g.d_counters);
   else
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1>), grid, block, lds, s, g.d_scene, a, rgb,
-                       canvas, g.d_counters);
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1, KIND>), grid, block, lds, s, g.d_scene,
+                       a, rgb, canvas, g.d_counters);
+}
+template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
+void launch_kind(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+                 double* canvas) {
+  /* kernels specialised for the primitive kinds the scene holds; the BVH kernels always have triangles */
+  if (!BVH && g.scene.n_tris == 0)
+    launch_stage<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1>(stage, lds, grid, s, a, rgb, canvas);
+  else if (g.scene.n_spheres == 0)
+    launch_stage<COUNT, BVH, REFLECT, F64OUT, 2>(stage, lds, grid, s, a, rgb, canvas);
+  else
+    launch_stage<COUNT, BVH, REFLECT, F64OUT, 0>(stage, lds, grid, s, a, rgb, canvas);
 }
 template <bool COUNT, bool BVH, bool REFLECT>
 void launch_f64(bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
                 double* canvas) {
-  if (f64) launch_stage<COUNT, BVH, REFLECT, true>(stage, lds, grid, s, a, rgb, canvas);
-  else launch_stage<COUNT, BVH, REFLECT, false>(stage, lds, grid, s, a, rgb, canvas);
+  if (f64) launch_kind<COUNT, BVH, REFLECT, true>(stage, lds, grid, s, a, rgb, canvas);
+  else launch_kind<COUNT, BVH, REFLECT, false>(stage, lds, grid, s, a, rgb, canvas);
 }
 template <bool COUNT, bool BVH>
 void launch_refl(bool reflect, bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a,

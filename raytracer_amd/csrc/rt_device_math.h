@@ -57,6 +57,21 @@ __device__ __forceinline__ d3 div3_by(d3 a, double m) {
   }
   return mk3(a.x / m, a.y / m, a.z / m);
 }
+/* two quotients by one divisor, same construction */
+__device__ __forceinline__ void div2_by(double a, double b, double m, double& qa, double& qb) {
+  const double am = fabs(m);
+  if (div_fast_ok(a) && div_fast_ok(b) && am > 1e-100 && am < 1e100) {
+    double y = __builtin_amdgcn_rcp(m);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    const double q0 = a * y, q1 = b * y;
+    qa = __builtin_fma(__builtin_fma(-m, q0, a), y, q0);
+    qb = __builtin_fma(__builtin_fma(-m, q1, b), y, q1);
+    return;
+  }
+  qa = a / m;
+  qb = b / m;
+}
 __device__ __forceinline__ d3 normalize3(d3 a) {                                                   /* :344 */
   return div3_by(a, mag3(a));
 }
