@@ -158,3 +158,49 @@ def test_errors_are_returned_not_raised_by_abort(hip, manifest):
     hip.upload(s)
     with pytest.raises(R.RtError):
         hip.render(accel=R._ffi.RT_ACCEL_BVH)
+
+
+# ---- BASELINE configs 4 and 5 at their full sizes ----
+def oracle_rows(scene, height, every, **kw):
+    """Rows y = 0, every, 2*every, ... from the CPU oracle (band_rows = 1, rank 0 of `every` ranks)."""
+    rows, st = O.render_rgb(scene, n_ranks=every, band_rows=1, rank=0, **kw)
+    return rows, np.arange(0, height, every)
+
+
+def test_config4_lighthouse_4k_reflections(hip):
+    """3840x2160 lighthouse, material.reflective = 0.3 on the mesh, depth 5: sampled rows against the oracle,
+    BVH image == exhaustive image, and N-band reassembly == full frame."""
+    W, H = 3840, 2160
+    s = R.stock_scene("lighthouse", W, H, tri_reflective=0.3)
+    hip.upload(s)
+    full, st = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    want, ys = oracle_rows(s, H, 108)
+    ex, npx = assert_image_parity(full[ys], want, "config 4 rows")
+    assert ex == npx
+    brute, st2 = hip.render(accel=R._ffi.RT_ACCEL_BRUTE, count_rays=True)
+    assert np.array_equal(full, brute) and st.rays == st2.rays
+    out = np.zeros_like(full)
+    for rank in range(8):
+        part, _ = hip.render(n_ranks=8, band_rows=16, rank=rank)
+        out[R.rank_row_map(H, 16, 8, rank)] = part
+    assert np.array_equal(out, full)
+    print(f"config 4: {st.rays} rays, BVH kernel {st.kernel_ms:.3f} ms = {st.rays / st.kernel_ms / 1e3:.0f} Mrays/s")
+
+
+def test_config5_cube_spheres_8k_16spp(hip):
+    """7680x4320, 4x4 sub-pixel grid, teapot.h mesh + six spheres with reflections: sampled rows against the
+    oracle and 8-band reassembly == full frame."""
+    W, H = 7680, 4320
+    s = R.stock_scene("cube_spheres", W, H, tri_reflective=0.3, sph_reflective=0.3)
+    hip.upload(s)
+    full, st = hip.render(spp_grid=4, count_rays=True)
+    assert st.rays_primary == W * H * 16
+    want, ys = oracle_rows(s, H, 1080, spp_grid=4)
+    ex, npx = assert_image_parity(full[ys], want, "config 5 rows")
+    assert ex == npx
+    out = np.zeros_like(full)
+    for rank in range(8):
+        part, _ = hip.render(spp_grid=4, n_ranks=8, band_rows=16, rank=rank)
+        out[R.rank_row_map(H, 16, 8, rank)] = part
+    assert np.array_equal(out, full)
+    print(f"config 5: {st.rays} rays, kernel {st.kernel_ms:.2f} ms = {st.rays / st.kernel_ms / 1e3:.0f} Mrays/s")
