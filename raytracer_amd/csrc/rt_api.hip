@@ -25,19 +25,29 @@ struct Context {
   bool have_scene = false;
   int device = -1;
   int n_cu = 256;
-  int tiles_per_block = 1;
+  int light_per_block = 4; /* background-only tiles per workgroup */
+  bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
   hipEvent_t tm0 = nullptr, tm1 = nullptr; /* caller-driven timer */
   DevScene scene{};
   bool reflective = false;
+  rt_camera host_camera{};
   void* d_spheres = nullptr;
   void* d_tris = nullptr;
   void* d_normals = nullptr;
   void* d_materials = nullptr;
   void* d_bvh = nullptr;
   DevScene* d_scene = nullptr; /* device copy of `scene` */
+  double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
+  /* tile order of the last plan and the parameters it was made for */
+  int32_t* d_tile_list = nullptr;
+  size_t tile_list_cap = 0;
+  long long plan_key[6] = {-1, -1, -1, -1, -1, -1};
+  int plan_heavy = 0, plan_tiles = 0;
+  unsigned long long scene_serial = 0;
+  const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
   void* d_tri_primary = nullptr;
   void* d_sph_primary = nullptr;
   unsigned long long* d_counters = nullptr;
@@ -97,14 +107,14 @@ void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderA
                   double* canvas) {
   const dim3 block(RT_TILE_W * RT_TILE_H);
   if (stage == 0)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, a, rgb,
-                       canvas, g.d_counters);
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, a, g.launch_tile_list,
+                       rgb, canvas, g.d_counters);
   else if (BVH)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       a, rgb, canvas, g.d_counters);
+                       a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1, KIND>), grid, block, lds, s, g.d_scene,
-                       a, rgb, canvas, g.d_counters);
+                       a, g.launch_tile_list, rgb, canvas, g.d_counters);
 }
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
 void launch_kind(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
@@ -151,6 +161,104 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
   }
 }
 
+/* general 4x4 inverse (Gauss-Jordan, partial pivoting); only used for the scheduling hint below */
+bool invert4(const double* m, double* out) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { a[r][c] = m[4 * r + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (std::fabs(a[piv][c]) < 1e-300) return false;
+    for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
+    const double d = a[c][c];
+    for (int k = 0; k < 8; ++k) a[c][k] /= d;
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+    }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = a[r][4 + c];
+  return true;
+}
+
+/* Pixel rectangle that contains every pixel whose camera rays can reach the mesh bounds: the bounds' eight
+ * corners through the view transform and the canvas mapping of ray_for_pixel (RayTracer.c:1538-1544) run
+ * backwards, plus a margin.  false = no useful rectangle (a corner beside or behind the camera). */
+bool mesh_pixel_rect(const rt_camera& cam, double& x0, double& y0, double& x1, double& y1) {
+  double view[16];
+  if (!invert4(cam.inv_view, view)) return false;
+  x0 = y0 = 1e300;
+  x1 = y1 = -1e300;
+  for (int k = 0; k < 8; ++k) {
+    const double w[3] = {(k & 1) ? g.mesh_hi[0] : g.mesh_lo[0], (k & 2) ? g.mesh_hi[1] : g.mesh_lo[1],
+                         (k & 4) ? g.mesh_hi[2] : g.mesh_lo[2]};
+    double c[3];
+    for (int r = 0; r < 3; ++r) c[r] = view[4 * r] * w[0] + view[4 * r + 1] * w[1] + view[4 * r + 2] * w[2] + view[4 * r + 3];
+    if (!(c[2] < -1e-6)) return false;
+    const double wx = c[0] / -c[2], wy = c[1] / -c[2];
+    const double px = (cam.half_width - wx) / cam.pixel_size - 0.5, py = (cam.half_height - wy) / cam.pixel_size - 0.5;
+    x0 = std::fmin(x0, px); x1 = std::fmax(x1, px);
+    y0 = std::fmin(y0, py); y1 = std::fmax(y1, py);
+  }
+  x0 -= 3.0; y0 -= 3.0; x1 += 3.0; y1 += 3.0;
+  return std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1);
+}
+
+/* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
+ * per workgroup).  Kept until the scene or the band layout changes. */
+int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a, int& n_blocks) {
+  const int W = g.scene.hsize;
+  const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+  const int n_tiles = tiles_x * tiles_y;
+  g.launch_tile_list = nullptr;
+  a.n_heavy = n_tiles;
+  a.light_per_block = 1;
+  n_blocks = n_tiles;
+  double x0, y0, x1, y1;
+  /* with spheres in the world any pixel may be expensive; without triangles there is nothing to sort by */
+  if (!g.tile_plan || g.scene.n_spheres > 0 || g.scene.n_tris == 0 || g.light_per_block <= 1) return RT_OK;
+  if (!mesh_pixel_rect(g.host_camera, x0, y0, x1, y1)) return RT_OK;
+  const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
+                            g.light_per_block};
+  if (memcmp(key, g.plan_key, sizeof key) != 0) {
+    std::vector<int32_t> heavy, light;
+    for (int ty = 0; ty < tiles_y; ++ty) {
+      /* image rows covered by this tile row (bands make packed rows non-contiguous in y) */
+      int ymin = 1 << 30, ymax = -1;
+      for (int r = ty * RT_TILE_H; r < (ty + 1) * RT_TILE_H && r < rows; ++r) {
+        const int y = rt_hip_rank_row_to_y(r, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank);
+        ymin = y < ymin ? y : ymin;
+        ymax = y > ymax ? y : ymax;
+      }
+      const bool row_hit = ymax >= y0 && ymin <= y1;
+      for (int tx = 0; tx < tiles_x; ++tx) {
+        const bool hit = row_hit && (tx + 1) * RT_TILE_W - 1 >= x0 && tx * RT_TILE_W <= x1;
+        (hit ? heavy : light).push_back(ty * tiles_x + tx);
+      }
+    }
+    g.plan_heavy = (int)heavy.size();
+    g.plan_tiles = n_tiles;
+    heavy.insert(heavy.end(), light.begin(), light.end());
+    if ((size_t)n_tiles > g.tile_list_cap) {
+      if (g.d_tile_list) (void)hipFree(g.d_tile_list);
+      g.d_tile_list = nullptr;
+      g.tile_list_cap = 0;
+      HIP_TRY(hipMalloc((void**)&g.d_tile_list, sizeof(int32_t) * (size_t)n_tiles));
+      g.tile_list_cap = (size_t)n_tiles;
+    }
+    HIP_TRY(hipMemcpyAsync(g.d_tile_list, heavy.data(), sizeof(int32_t) * (size_t)n_tiles, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
+    memcpy(g.plan_key, key, sizeof key);
+  }
+  g.launch_tile_list = g.d_tile_list;
+  a.n_heavy = g.plan_heavy;
+  a.light_per_block = g.light_per_block;
+  n_blocks = g.plan_heavy + (n_tiles - g.plan_heavy + g.light_per_block - 1) / g.light_per_block;
+  return RT_OK;
+}
+
 int check_params(const rt_render_params* p) {
   if (!p) return RT_ERR_INVALID;
   if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
@@ -186,8 +294,12 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   if (rows > 0) {
     if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
-    a.tiles_per_block = g.tiles_per_block;
-    dim3 grid((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block));
+    int n_blocks = 0;
+    const int prc = plan_tiles(p, rows, s, a, n_blocks);
+    if (prc != RT_OK) return prc;
+    a.pad = 0;
+    (void)n_tiles;
+    dim3 grid((unsigned)n_blocks);
     if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
     launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
@@ -241,10 +353,11 @@ int rt_hip_init(int device) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("RT_HIP_LDS")) g.use_lds = atoi(e) != 0; /* tuning knob: 0 = read primitives from global memory */
-  if (const char* e = getenv("RT_HIP_TILES_PER_BLOCK")) { /* tuning knob */
+  if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) { /* tuning knob */
     const int v = atoi(e);
-    if (v >= 1 && v <= 64) g.tiles_per_block = v;
+    if (v >= 1 && v <= 64) g.light_per_block = v;
   }
+  if (const char* e = getenv("RT_HIP_TILE_PLAN")) g.tile_plan = atoi(e) != 0; /* tuning knob: 0 = row-major tiles */
   g.device = device;
   g.ready = true;
   return RT_OK;
@@ -385,6 +498,8 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     d.box_lo[c] = nt ? std::nextafterf((float)(blo[c] - pad), -INFINITY) : 0.f;
     d.box_hi[c] = nt ? std::nextafterf((float)(bhi[c] + pad), INFINITY) : 0.f;
   }
+  for (int c = 0; c < 3; ++c) { g.mesh_lo[c] = blo[c] - pad; g.mesh_hi[c] = bhi[c] + pad; }
+  g.scene_serial++;
   d.tri_primary = (const DevTriPrimary*)g.d_tri_primary;
   d.sph_primary = (const DevSpherePrimary*)g.d_sph_primary;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
@@ -400,6 +515,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   d.tri_normals = (const double*)g.d_normals;
   d.materials = (const rt_material*)g.d_materials;
   d.bvh = (const rt_bvh_node*)g.d_bvh;
+  g.host_camera = sc->camera;
   g.reflective = false;
   for (int i = 0; i < sc->n_materials; ++i)
     if (!(std::fabs(sc->materials[i].reflective - 0.0) < RT_EPSILON)) g.reflective = true;
@@ -502,6 +618,7 @@ void rt_hip_shutdown(void) {
   free_scene();
   if (g.d_counters) (void)hipFree(g.d_counters);
   if (g.d_scene) (void)hipFree(g.d_scene);
+  if (g.d_tile_list) (void)hipFree(g.d_tile_list);
   if (g.d_rgb) (void)hipFree(g.d_rgb);
   if (g.d_canvas) (void)hipFree(g.d_canvas);
   if (g.ev0) (void)hipEventDestroy(g.ev0);
