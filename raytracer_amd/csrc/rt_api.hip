@@ -33,6 +33,7 @@ struct Context {
   hipEvent_t tm0 = nullptr, tm1 = nullptr; /* caller-driven timer */
   DevScene scene{};
   bool reflective = false;
+  bool bvh_single_leaf = false;
   rt_camera host_camera{};
   void* d_spheres = nullptr;
   void* d_tris = nullptr;
@@ -100,7 +101,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
-constexpr int kMaxLdsBvhNodes = 1536; /* 1536 * 32 B = 48 KiB */
+constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT, int KIND>
 void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
@@ -149,7 +150,7 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
       lds = (size_t)g.scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
     } else if (bvh && g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
       stage = 2;
-      lds = (size_t)g.scene.n_bvh_nodes * sizeof(rt_bvh_node);
+      lds = (size_t)g.scene.n_bvh_nodes * sizeof(DevBvh2);
     }
   }
   if (count) {
@@ -268,7 +269,8 @@ int check_params(const rt_render_params* p) {
   if (p->n_ranks < 1 || p->rank < 0 || p->rank >= p->n_ranks) return RT_ERR_INVALID;
   if (p->n_ranks > 1 && p->band_rows < 1) return RT_ERR_INVALID;
   if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH) return RT_ERR_INVALID;
-  if (p->accel == RT_ACCEL_BVH && g.scene.n_bvh_nodes == 0 && g.scene.n_tris > 0) return RT_ERR_NOT_READY;
+  if (p->accel == RT_ACCEL_BVH && g.scene.n_bvh_nodes == 0 && g.scene.n_tris > 0 && !g.bvh_single_leaf)
+    return RT_ERR_NOT_READY;
   return RT_OK;
 }
 
@@ -395,14 +397,19 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   }
   bool use_bvh = sc->n_bvh_nodes > 0 && sc->bvh_nodes && sc->bvh_tri && nt > 0;
   int depth = 0;
+  int n_bvh_inner = 0;
+  g.bvh_single_leaf = use_bvh && sc->bvh_nodes[0].right < 0;
+  if (g.bvh_single_leaf) use_bvh = false; /* nothing to walk: the exhaustive loop is the walk */
   if (use_bvh) {
     depth = bvh_depth(sc->bvh_nodes, sc->n_bvh_nodes, 0, 0);
     if (depth > RT_BVH_STACK) return RT_ERR_TOO_LARGE;
+    if (nt >= (1 << 27)) return RT_ERR_TOO_LARGE;
     std::vector<char> used((size_t)nt, 0);
     for (int i = 0; i < sc->n_bvh_nodes; ++i) {
       const rt_bvh_node& n = sc->bvh_nodes[i];
       if (n.right < 0) {
         if (n.left < 0 || (long long)n.left - n.right > nt) return RT_ERR_INVALID;
+        if (-n.right > 7) return RT_ERR_TOO_LARGE; /* the device leaf encoding holds up to 7 triangles */
       } else if (n.left <= 0 || n.left >= sc->n_bvh_nodes || n.right <= 0 || n.right >= sc->n_bvh_nodes) {
         return RT_ERR_INVALID;
       }
@@ -481,9 +488,45 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if ((rc = upload(&g.d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&g.d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&g.d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
-  if (use_bvh &&
-      (rc = upload(&g.d_bvh, sc->bvh_nodes, sizeof(rt_bvh_node) * (size_t)sc->n_bvh_nodes)) != RT_OK)
-    return rc;
+  /* device BVH: inner nodes only, each with both children's boxes.  The host boxes get an extra pad of
+   * ~500 float ulps of the largest coordinate in play (mesh, camera, light), far more than rounding the ray
+   * origin, its reciprocal direction and the slab products to single precision can move a slab distance. */
+  std::vector<DevBvh2> hb;
+  if (use_bvh) {
+    const double pad2 = 3e-5 * amax;
+    std::vector<int> inner_index((size_t)sc->n_bvh_nodes, -1);
+    int n_inner = 0;
+    for (int i = 0; i < sc->n_bvh_nodes; ++i)
+      if (sc->bvh_nodes[i].right >= 0) inner_index[i] = n_inner++;
+    hb.resize((size_t)(n_inner > 0 ? n_inner : 1));
+    auto child_ref = [&](int c) -> int32_t {
+      const rt_bvh_node& n = sc->bvh_nodes[c];
+      if (n.right >= 0) return inner_index[c];
+      return ~((n.left << 3) | (-n.right));
+    };
+    for (int i = 0; i < sc->n_bvh_nodes; ++i) {
+      const rt_bvh_node& n = sc->bvh_nodes[i];
+      if (n.right < 0) continue;
+      DevBvh2& d2 = hb[(size_t)inner_index[i]];
+      const int ch[2] = {n.left, n.right};
+      float lo[2][3], hi[2][3];
+      for (int k = 0; k < 2; ++k)
+        for (int c = 0; c < 3; ++c) {
+          lo[k][c] = std::nextafterf((float)((double)sc->bvh_nodes[ch[k]].lo[c] - pad2), -INFINITY);
+          hi[k][c] = std::nextafterf((float)((double)sc->bvh_nodes[ch[k]].hi[c] + pad2), INFINITY);
+        }
+      int32_t r0 = child_ref(ch[0]), r1 = child_ref(ch[1]);
+      float f0, f1;
+      memcpy(&f0, &r0, 4);
+      memcpy(&f1, &r1, 4);
+      d2.q[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], f0);
+      d2.q[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], f1);
+      d2.q[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], 0.f);
+      d2.q[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], 0.f);
+    }
+    n_bvh_inner = n_inner;
+    if ((rc = upload(&g.d_bvh, hb.data(), sizeof(DevBvh2) * (size_t)n_inner)) != RT_OK) return rc;
+  }
 
   DevScene& d = g.scene;
   d.pixel_size = sc->camera.pixel_size;
@@ -508,13 +551,13 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   d.vsize = sc->camera.vsize;
   d.n_spheres = ns;
   d.n_tris = nt;
-  d.n_bvh_nodes = use_bvh ? sc->n_bvh_nodes : 0;
+  d.n_bvh_nodes = use_bvh ? n_bvh_inner : 0;
   d.bvh_depth = depth;
   d.spheres = (const DevSphere*)g.d_spheres;
   d.tris = (const DevTri*)g.d_tris;
   d.tri_normals = (const double*)g.d_normals;
   d.materials = (const rt_material*)g.d_materials;
-  d.bvh = (const rt_bvh_node*)g.d_bvh;
+  d.bvh = (const DevBvh2*)g.d_bvh;
   g.host_camera = sc->camera;
   g.reflective = false;
   for (int i = 0; i < sc->n_materials; ++i)

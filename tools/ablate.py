@@ -15,7 +15,7 @@ for scene in scenes:
     MODES = ((1, "store only"), (2, "ray generation"), (3, "primary hit"), (4, "no shadow ray"), (5, "no lighting"), (0, "full")) if os.environ.get("RT_ABLATE") else ((0, "full"),)
     for mode, name in MODES:
         for accel, an in ((R._ffi.RT_ACCEL_BRUTE, "brute"), (R._ffi.RT_ACCEL_BVH, "bvh")):
-            if mode != 0 and an == "bvh":
+            if mode != 0 and an == "bvh" and not os.environ.get("RT_ABLATE_BVH"):
                 continue
             if an == "bvh" and scene == "spheres":
                 continue
