@@ -108,14 +108,15 @@ void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderA
                   double* canvas) {
   const dim3 block(RT_TILE_W * RT_TILE_H);
   if (stage == 0)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, a, g.launch_tile_list,
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, (const DevSphere*)g.d_spheres,
+                       (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list,
                        rgb, canvas, g.d_counters);
   else if (BVH)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       a, g.launch_tile_list, rgb, canvas, g.d_counters);
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1, KIND>), grid, block, lds, s, g.d_scene,
-                       a, g.launch_tile_list, rgb, canvas, g.d_counters);
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
 }
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
 void launch_kind(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
