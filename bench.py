@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One step = one render() of the frame: every rank traces its round-robin row
-bands on its own MI355X and (N > 1) the 8-bit rows are gathered to rank 0 with
-RCCL.  The scene is uploaded before the timed region; nothing crosses PCIe
+bands on its own MI355X and (N > 1) the 8-bit rows are exchanged with RCCL so
+that frame f is complete on rank f % N (one all-to-all per group of frames).  The scene is uploaded before the timed region; nothing crosses PCIe
 inside it.  Rank 0 prints one JSON line.
 
   value        total rays (primary + shadow + secondary, the reference's
@@ -30,7 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import raytracer_amd as R  # noqa: E402
-from raytracer_amd.dist import BandGather, default_band_rows  # noqa: E402
+from raytracer_amd.dist import FrameExchange, default_band_rows  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "cube"  # render_some_triangles + the teapot.h mesh (12 triangles), RayTracer.c:6727
@@ -40,7 +40,19 @@ FLOP_PER_SPHERE_TEST = 63   # two affine mat-vec + quadratic, RayTracer.c:898-94
 FLOP_PER_BOX_TEST = 18      # slab test (BVH node or mesh bounds)
 FLOP_PER_PRIMARY_RAY = 30   # ray_for_pixel, RayTracer.c:1535
 FLOP_PER_SHADED_HIT = 80    # prepare_computations + lighting (+ 1 pow), RayTracer.c:1360, 1273
-PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 128 lanes x 2 x 2.4 GHz)
+PEAK_FP64_NO_FMA_TFLOPS = 39.3  # FP64 vector: 78.6 with FMA, half of it for a mul/add-only stream
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the headline kernel, from the committed summary of the PMC passes (a bench run
+    cannot collect hardware counters itself); None when no summary is there."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_cube_1080p.json")
+    try:
+        d = json.load(open(path))
+        return int(d["derived_hbm_read_bytes_corrected_x2"] + d["derived_hbm_write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_flops(st):
@@ -70,9 +82,13 @@ def side_measurements(hip, dev, steps=100):
             hip.render_device(buf.data_ptr(), p)
         hip.timer_stop()
         ms = hip.timer_ms() / n
-        fl = algorithmic_flops(st)
+        executed = algorithmic_flops(st)
+        sc = hip.scene_counts()
+        exhaustive = st.rays * (sc[1] * FLOP_PER_TRI_TEST + sc[0] * FLOP_PER_SPHERE_TEST)
+        fl = exhaustive if st.accel_used == R._ffi.RT_ACCEL_BRUTE else executed
         out[name] = {"rays": st.rays, "kernel_ms": round(ms, 5), "mrays_s": round(st.rays / ms / 1e3, 1),
-                     "tflops_algorithmic": round(fl / ms / 1e9, 3), "tri_tests": st.prim_tests - st.sphere_tests,
+                     "tflops_algorithmic": round(fl / ms / 1e9, 3), "tflops_executed": round(executed / ms / 1e9, 3),
+                     "tri_tests": st.prim_tests - st.sphere_tests,
                      "sphere_tests": st.sphere_tests, "box_tests": st.node_tests}
     return out
 
@@ -134,62 +150,63 @@ def main():
     scene = R.stock_scene(SCENE, WIDTH, HEIGHT)
     hip.upload(scene)
     band_rows = default_band_rows(HEIGHT, world)
-    bg = BandGather(HEIGHT, WIDTH, band_rows, world, rank, dev, slots=2)
+    # Frame f of the run is put together on rank f % world; a group of 4 * world frames moves in one
+    # all-to-all (RCCL) while the next group renders into the other buffer set.
+    fx = FrameExchange(HEIGHT, WIDTH, band_rows, world, rank, dev, rounds=4, slots=2)
     p = R.make_params(max_depth=5, spp_grid=1, accel=R._ffi.RT_ACCEL_AUTO, band_rows=band_rows, n_ranks=world, rank=rank)
     stream = torch.cuda.current_stream().cuda_stream
 
     # rays of this rank's rows (counting variant of the kernel, outside the timed region)
     pc = R.make_params(max_depth=5, count_rays=True, band_rows=band_rows, n_ranks=world, rank=rank)
     st = R._ffi.Stats()
-    hip.render_device(bg.local.data_ptr(), pc, stream=stream, stats=st)
+    hip.render_device(fx.target(0, 0).data_ptr(), pc, stream=stream, stats=st)
     my_rays = torch.tensor([st.rays, st.prim_tests], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(my_rays)
     total_rays, _ = [int(x) for x in my_rays.tolist()]
     accel_used = "bvh" if st.accel_used == R._ffi.RT_ACCEL_BVH else "brute"
 
-    # Two buffer slots: frame i renders while the gather of frame i - 1 is in flight; a slot is reused only
-    # after its previous gather has been waited for (stream-ordered), and every frame's image is assembled.
-    pending = [None, None]
-    frame = [0]
-
-    def step():
-        k = frame[0] % 2
-        frame[0] += 1
-        if pending[k] is not None:
-            bg.finish(pending[k], k)
-        hip.render_device(bg.locals[k].data_ptr(), p, stream=stream)
-        if world > 1:
-            pending[k] = bg.gather_async(k)
-
-    def drain():
-        for k in range(2):
+    def run(n_steps):
+        """n_steps frames: render, exchange, assemble.  Returns how many complete frames this rank ends up holding."""
+        pending = [None, None]
+        held = 0
+        f, slot = 0, 0
+        while f < n_steps:
+            if pending[slot] is not None:  # the slot's previous group must have left before it is overwritten
+                held += len(fx.finish(pending[slot], slot))
+            n = min(fx.group, n_steps - f)
+            for j in range(n):
+                hip.render_device(fx.target(slot, j).data_ptr(), p, stream=stream)
+            pending[slot] = fx.exchange_async(slot, n)
+            f += n
+            slot ^= 1
+        for k in (slot, slot ^ 1):
             if pending[k] is not None:
-                bg.finish(pending[k], k)
-                pending[k] = None
+                held += len(fx.finish(pending[k], k))
+        return held
 
-    for _ in range(a.warmup):
-        step()
-    drain()
+    run(a.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hip.timer_start(stream)
-    for _ in range(a.steps):
-        step()
-    drain()
+    held = run(a.steps)
     hip.timer_stop(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     ev_ms = hip.timer_ms()
+    frames_held = torch.tensor([held], dtype=torch.float64, device="cpu" if rehearse else dev)
+    if world > 1:
+        dist.all_reduce(frames_held)
+    assert int(frames_held.item()) == a.steps, "every timed frame must have been put together on some rank"
     if world > 1:
         # the kernel alone (no gather between launches), for the roofline line
         hip.timer_start(stream)
         for _ in range(50):
-            hip.render_device(bg.locals[0].data_ptr(), p, stream=stream)
+            hip.render_device(fx.target(0, 0).data_ptr(), p, stream=stream)
         hip.timer_stop(stream)
         ev_ms = hip.timer_ms() / 50 * a.steps
     t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -202,7 +219,14 @@ def main():
         flops_per_launch = algorithmic_flops(st)
         exhaustive_flops = st.rays * (scene.n_tris * FLOP_PER_TRI_TEST + scene.n_spheres * FLOP_PER_SPHERE_TEST)
         kernel_ms = ev_ms / a.steps  # HIP events on the launch stream around the K launches
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        # Algorithmic FLOPs of a launch.  Exhaustive kernel: rays x primitives x the full-path figure (what the
+        # reference's loop over every object costs); BVH kernel: the tests the walk actually made (counted).
+        if accel_used == "brute":
+            algorithmic = exhaustive_flops
+        else:
+            algorithmic = flops_per_launch
+        achieved = algorithmic / (kernel_ms * 1e-3) / 1e12
+        executed = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080 teapot scene; % of FP32 VALU peak",
             "value": round(total_rays * a.steps / dt / 1e6, 2),
@@ -219,17 +243,24 @@ def main():
             "config": {"workload": f"teapot.h mesh (12 triangles), render_some_triangles camera/light, {WIDTH}x{HEIGHT}, "
                                    "1 spp, depth 5", "rays_per_frame": total_rays, "accel": accel_used,
                        "parallelism": f"row bands of {band_rows} rows round-robin over {world} rank(s)"
-                                      + (", one RCCL gather to rank 0 per frame" if world > 1 else "")},
+                                      + (f"; frame f is put together on rank f % {world}, one RCCL all-to-all per "
+                                         f"{fx.group} frames" if world > 1 else "")},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
-                         "kernel": "rt_trace_kernel", "kernel_ms": round(kernel_ms, 5),
-                         "flops_per_launch": flops_per_launch,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": pmc_traffic_bytes(), "kernel": "rt_trace_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_flops_per_launch": algorithmic,
+                         "executed_tflops": round(executed, 3), "executed_flops_per_launch": flops_per_launch,
+                         "fp64_no_fma_ceiling_tflops": PEAK_FP64_NO_FMA_TFLOPS,
+                         "frac_of_fp64_no_fma_ceiling": round(achieved / PEAK_FP64_NO_FMA_TFLOPS, 4),
                          "counters": {"tri_tests": st.prim_tests - st.sphere_tests, "sphere_tests": st.sphere_tests,
                                       "box_tests": st.node_tests, "primary": st.rays_primary, "shaded": st.rays_shadow},
-                         "exhaustive_equivalent_tflops": round(exhaustive_flops / (kernel_ms * 1e-3) / 1e12, 3),
-                         "note": "FLOPs = 30/primary ray + 80/shaded hit + 45/triangle test + 63/sphere test + 18/box test "
-                                 "actually executed (counting build of the same kernel); Arithmetic is FP64 without FMA (parity), priced against the FP32 "
-                                 "vector peak; exhaustive_equivalent = rays x 12 triangles x 45 over the same time"},
+                         "note": "bound: vector ALU (the scene sits in LDS/scalar cache, 3 B per pixel are written). "
+                                 "achieved = algorithmic FLOPs / kernel time: rays x 12 triangles x 45 for this exhaustive "
+                                 "kernel; executed = 30/primary ray + 80/shaded hit + 45/triangle test + 18/box test the "
+                                 "kernel really ran (a bounds test lets most rays skip the triangle loop). The arithmetic "
+                                 "is FP64 mul/add without FMA (bit parity with the reference), whose ceiling is 1/4 of the "
+                                 "FP32 vector peak priced here. traffic = HBM bytes per launch from separate rocprofv3 "
+                                 "--pmc passes over the same launch (profiles/), FETCH_SIZE x2 + WRITE_SIZE"},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total_rays)

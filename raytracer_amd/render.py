@@ -45,6 +45,10 @@ class HipRenderer:
         self.width, self.height = scene.camera.hsize, scene.camera.vsize
         return self
 
+    def scene_counts(self):
+        """(spheres, triangles) of the uploaded scene."""
+        return (self._scene.n_spheres, self._scene.n_tris) if self._scene is not None else (0, 0)
+
     def rank_rows(self, p):
         n = self._L.rt_hip_rank_rows(self.height, p.band_rows, p.n_ranks, p.rank)
         if n < 0:

@@ -58,6 +58,58 @@ def test_two_rank_bands_gather_to_the_one_rank_image(tmp_path, world, band_rows)
     assert np.array_equal(got, want)
 
 
+def _exchange_worker(rank, world, port, band_rows, rounds, n_frames, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib as O
+    import raytracer_amd as R
+    from raytracer_amd.dist import FrameExchange
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 45, 37
+    # every frame is a different image, so a frame that ends up on the wrong rank or in the wrong slot shows
+    scenes = [R.stock_scene("cube_spheres", W, H, tri_reflective=0.1 * f, sph_reflective=0.05 * f) for f in range(n_frames)]
+    fx = FrameExchange(H, W, band_rows, world, rank, torch.device("cpu"), rounds=rounds, slots=2)
+    got = {}
+    pending = [None, None]
+    base = [0, 0]
+    f, slot = 0, 0
+    while f < n_frames:
+        if pending[slot] is not None:
+            for j, img in fx.finish(pending[slot], slot):
+                got[base[slot] + j] = img.numpy().copy()
+        n = min(fx.group, n_frames - f)
+        for j in range(n):
+            part, _ = O.render_rgb(scenes[f + j], n_ranks=world, band_rows=band_rows, rank=rank)
+            fx.target(slot, j)[: fx.n_local] = torch.from_numpy(part)
+        pending[slot], base[slot] = fx.exchange_async(slot, n), f
+        f += n
+        slot ^= 1
+    for k in (slot, slot ^ 1):
+        if pending[k] is not None:
+            for j, img in fx.finish(pending[k], k):
+                got[base[k] + j] = img.numpy().copy()
+    assert sorted(got) == [i for i in range(n_frames) if i % world == rank]
+    for i, img in got.items():
+        full, _ = O.render_rgb(scenes[i])
+        assert np.array_equal(img, full), f"frame {i} on rank {rank}"
+    count = torch.tensor([len(got)], dtype=torch.int64)
+    dist.all_reduce(count)
+    if rank == 0:
+        with open(os.path.join(out_dir, "frames.txt"), "w") as fh:
+            fh.write(str(int(count.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,band_rows,rounds,n_frames", [(2, 4, 2, 9), (3, 1, 1, 4), (1, 1, 2, 3)])
+def test_frame_exchange_puts_frame_f_on_rank_f_mod_n(tmp_path, world, band_rows, rounds, n_frames):
+    mp.spawn(_exchange_worker, args=(world, _free_port(), band_rows, rounds, n_frames, str(tmp_path)), nprocs=world,
+             join=True)
+    assert int(open(tmp_path / "frames.txt").read()) == n_frames
+
+
 def test_band_helpers():
     from raytracer_amd.dist import default_band_rows, rank_rows
 

@@ -12,8 +12,14 @@ buf = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda:0")
 scenes = sys.argv[1:] or ["cube", "spheres", "lighthouse"]
 for scene in scenes:
     r.upload(R.stock_scene(scene, 1920, 1080))
-    MODES = ((1, "store only"), (2, "ray generation"), (3, "primary hit"), (4, "no shadow ray"), (5, "no lighting"), (0, "full")) if os.environ.get("RT_ABLATE") else ((0, "full"),)
+    if os.environ.get("RT_ABLATE_MODES"):
+        want = {int(x) for x in os.environ["RT_ABLATE_MODES"].split(",")}
+    else:
+        want = None
+    MODES = ((1, "store only"), (6, "store black"), (2, "ray generation"), (3, "primary hit"), (4, "no shadow ray"), (5, "no lighting"), (0, "full")) if os.environ.get("RT_ABLATE") else ((0, "full"),)
     for mode, name in MODES:
+        if want is not None and mode not in want:
+            continue
         for accel, an in ((R._ffi.RT_ACCEL_BRUTE, "brute"), (R._ffi.RT_ACCEL_BVH, "bvh")):
             if mode != 0 and an == "bvh" and not os.environ.get("RT_ABLATE_BVH"):
                 continue

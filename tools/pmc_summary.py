@@ -18,8 +18,9 @@ summ["_kernel"] = meta
 d = summ
 if "SQ_WAVE_CYCLES" in d and "SQ_ACTIVE_INST_VALU" in d:
     d["derived_valu_active_share_of_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
-if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"]:
-    d["derived_active_lanes_per_valu_cycle_of_64"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 4.0
+if "SQ_THREAD_CYCLES_VALU" in d and d.get("SQ_INSTS_VALU"):
+    # thread-cycles per issued VALU instruction: 64 = every lane active in every instruction
+    d["derived_active_lanes_per_valu_inst_of_64"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"]
 if "FETCH_SIZE" in d:
     d["derived_hbm_read_bytes_corrected_x2"] = d["FETCH_SIZE"] * 1024 * 2
 if "WRITE_SIZE" in d:
