@@ -93,6 +93,30 @@ def side_measurements(hip, dev, steps=100):
     return out
 
 
+def ppm_measurements(hip, dev, steps=50):
+    """The step after the path: write_canvas_to_file's P3 text (RayTracer.c:1333) formatted on the device.
+    HBM-bound; algorithmic bytes = the image read twice (lengths, then text) + the text written."""
+    out = {}
+    for (w, h) in ((WIDTH, HEIGHT), (7680, 4320)):
+        img = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device=dev)
+        cap = hip.ppm_capacity(w, h)
+        text = torch.empty(cap, dtype=torch.uint8, device=dev)
+        n = hip.format_ppm_device(img.data_ptr(), w, h, text.data_ptr(), cap)
+        for _ in range(3):
+            hip.format_ppm_device(img.data_ptr(), w, h, text.data_ptr(), cap, wait=False)
+        hip.timer_start()
+        for _ in range(steps):
+            hip.format_ppm_device(img.data_ptr(), w, h, text.data_ptr(), cap, wait=False)
+        hip.timer_stop()
+        ms = hip.timer_ms() / steps
+        nbytes = 2 * 3 * w * h + n
+        out[f"{w}x{h}"] = {"text_bytes": n, "ms": round(ms, 5), "roofline": {
+            "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes}}
+        del img, text
+    return out
+
+
 def cpu_baseline(rays_expected):
     """The reference (or, failing that, the CPU port) on the same frame, one core of this host."""
     ref = os.path.join(ROOT, "oracle", "_ref", "rt_ref_harness_timing")
@@ -266,6 +290,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(total_rays)
         if world == 1 and not a.no_side:
             line["other_scenes_1080p"] = side_measurements(hip, dev)
+            line["ppm_text_on_device_random_image"] = ppm_measurements(hip, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

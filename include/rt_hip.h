@@ -180,6 +180,37 @@ int rt_hip_render_device(const rt_render_params* params, void* rgb_out_device, v
  * memory.  For parity diagnostics. */
 int rt_hip_render_f64(const rt_render_params* params, double* canvas_out, rt_stats* stats);
 
+/* ---- the image file, formatted on the device ----
+ * write_canvas_to_file() (RayTracer.c:1333-1348) prints the canvas as ASCII P3:
+ * "P3\n<W> <H>\n255\n", then per pixel (y outer, x inner) "%d %d %d \n".  These
+ * entry points produce exactly those bytes from an 8-bit image in device
+ * memory (what rt_hip_render_device leaves there); the caller writes them to
+ * the file with one fwrite. */
+
+/* Upper bound of the text length for a width x height image (header + 13 bytes per pixel). */
+size_t rt_hip_ppm_capacity(int width, int height);
+
+/* rgb_device: width * height * 3 bytes, 4-byte aligned; text_device: at least
+ * rt_hip_ppm_capacity() bytes of device memory, 16-byte aligned.  Enqueued on
+ * `stream` (NULL = the library's).  bytes_out != NULL: waits and stores the
+ * length of the text; NULL: returns at once (the length can be had later from
+ * rt_hip_ppm_last_length, which waits). */
+int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void* text_device, size_t capacity,
+                             size_t* bytes_out, void* stream);
+int rt_hip_ppm_last_length(size_t* bytes_out);
+
+/* The same into host memory: formats into a library-owned device buffer and
+ * copies the text (not the 13-bytes-per-pixel bound) to text_host.
+ * RT_ERR_TOO_LARGE with *bytes_out = needed size if capacity is too small. */
+int rt_hip_format_ppm(const void* rgb_device, int width, int height, char* text_host, size_t capacity,
+                      size_t* bytes_out);
+
+/* render(c, &w) followed by write_canvas_to_file()'s formatting, all on the
+ * device: the whole frame (n_ranks must be 1) arrives in text_host as the
+ * bytes of canvas.ppm.  stats may be NULL. */
+int rt_hip_render_ppm(const rt_render_params* params, char* text_host, size_t capacity, size_t* bytes_out,
+                      rt_stats* stats);
+
 /* Number of image rows that belong to `rank` (see rt_render_params). */
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank);
 

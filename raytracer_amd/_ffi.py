@@ -180,6 +180,14 @@ def hip_lib():
         L.rt_hip_rank_row_to_y.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_hip_event_record.argtypes = [C.c_int, C.c_void_p]
         L.rt_hip_event_elapsed_ms.argtypes = [C.POINTER(C.c_double)]
+        L.rt_hip_ppm_capacity.argtypes = [C.c_int, C.c_int]
+        L.rt_hip_ppm_capacity.restype = C.c_size_t
+        L.rt_hip_format_ppm_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                               C.POINTER(C.c_size_t), C.c_void_p]
+        L.rt_hip_ppm_last_length.argtypes = [C.POINTER(C.c_size_t)]
+        L.rt_hip_format_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.rt_hip_render_ppm.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                        C.POINTER(Stats)]
         L.rt_hip_shutdown.restype = None
         L.rt_hip_strerror.argtypes = [C.c_int]
         L.rt_hip_strerror.restype = C.c_char_p
@@ -194,6 +202,11 @@ HIP_EXPORTS = [
     "rt_hip_render",
     "rt_hip_render_device",
     "rt_hip_render_f64",
+    "rt_hip_ppm_capacity",
+    "rt_hip_format_ppm_device",
+    "rt_hip_ppm_last_length",
+    "rt_hip_format_ppm",
+    "rt_hip_render_ppm",
     "rt_hip_rank_rows",
     "rt_hip_rank_row_to_y",
     "rt_hip_event_record",

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_kernels.hip.inc"
+#include "rt_ppm.hip.inc"
 
 namespace {
 
@@ -56,6 +57,15 @@ struct Context {
   size_t d_rgb_bytes = 0;
   double* d_canvas = nullptr;
   size_t d_canvas_bytes = 0;
+  /* P3 formatter: per-chunk lengths and offsets, library-owned text buffer, pinned word for the length */
+  unsigned* d_ppm_len = nullptr;
+  unsigned long long* d_ppm_off = nullptr;
+  size_t ppm_chunks_cap = 0;
+  unsigned char* d_ppm_text = nullptr;
+  size_t d_ppm_text_bytes = 0;
+  unsigned long long* h_ppm_total = nullptr; /* pinned */
+  hipStream_t ppm_stream = nullptr;          /* stream of the last formatting call */
+  bool ppm_pending = false;
 };
 
 Context g;
@@ -569,6 +579,111 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   return RT_OK;
 }
 
+size_t rt_hip_ppm_capacity(int width, int height) {
+  if (width < 0 || height < 0) return 0;
+  return 64 + (size_t)PPM_MAX_PX_TEXT * (size_t)width * (size_t)height;
+}
+
+int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void* text_device, size_t capacity,
+                             size_t* bytes_out, void* stream) {
+  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!rgb_device || !text_device || width < 0 || height < 0) return RT_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(rgb_device) & 3u) != 0 || (reinterpret_cast<uintptr_t>(text_device) & 15u) != 0)
+    return RT_ERR_INVALID;
+  if (capacity < rt_hip_ppm_capacity(width, height)) return RT_ERR_TOO_LARGE;
+  const long long n_px = (long long)width * height;
+  const long long n_chunks_ll = (n_px + PPM_CHUNK - 1) / PPM_CHUNK;
+  if (n_chunks_ll > (1ll << 30)) return RT_ERR_TOO_LARGE;
+  const int n_chunks = (int)n_chunks_ll;
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  PpmHeader hd;
+  memset(&hd, 0, sizeof hd);
+  hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
+  if (!g.h_ppm_total) HIP_TRY(hipHostMalloc((void**)&g.h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
+  if ((size_t)n_chunks + 1 > g.ppm_chunks_cap) {
+    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream));
+    if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
+    if (g.d_ppm_off) (void)hipFree(g.d_ppm_off);
+    g.d_ppm_len = nullptr;
+    g.d_ppm_off = nullptr;
+    g.ppm_chunks_cap = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
+    HIP_TRY(hipMalloc((void**)&g.d_ppm_off, sizeof(unsigned long long) * ((size_t)n_chunks + 1)));
+    g.ppm_chunks_cap = (size_t)n_chunks + 1;
+  }
+  if (n_chunks > 0) {
+    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
+                       (const unsigned char*)rgb_device, n_px, g.d_ppm_len);
+  }
+  hipLaunchKernelGGL(ppm_scan_kernel, dim3(1), dim3(PPM_SCAN_THREADS), 0, s, (const unsigned*)g.d_ppm_len, n_chunks,
+                     (unsigned long long)hd.len, g.d_ppm_off);
+  if (n_chunks > 0) {
+    hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
+                       (const unsigned char*)rgb_device, n_px, (const unsigned long long*)g.d_ppm_off, hd,
+                       (unsigned char*)text_device);
+  } else {
+    HIP_TRY(hipMemcpyAsync(text_device, hd.text, (size_t)hd.len, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); /* hd lives on this stack frame */
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(g.h_ppm_total, g.d_ppm_off + n_chunks, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  g.ppm_stream = s;
+  g.ppm_pending = true;
+  if (bytes_out) return rt_hip_ppm_last_length(bytes_out);
+  return RT_OK;
+}
+
+int rt_hip_ppm_last_length(size_t* bytes_out) {
+  if (!g.ready || !g.h_ppm_total) return RT_ERR_NOT_READY;
+  if (!bytes_out) return RT_ERR_INVALID;
+  if (g.ppm_pending) {
+    HIP_TRY(hipStreamSynchronize(g.ppm_stream));
+    g.ppm_pending = false;
+  }
+  *bytes_out = (size_t)*g.h_ppm_total;
+  return RT_OK;
+}
+
+int rt_hip_format_ppm(const void* rgb_device, int width, int height, char* text_host, size_t capacity,
+                      size_t* bytes_out) {
+  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!text_host && capacity > 0) return RT_ERR_INVALID;
+  const size_t need = rt_hip_ppm_capacity(width, height);
+  if (need > g.d_ppm_text_bytes) {
+    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream));
+    if (g.d_ppm_text) (void)hipFree(g.d_ppm_text);
+    g.d_ppm_text = nullptr;
+    g.d_ppm_text_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_ppm_text, need));
+    g.d_ppm_text_bytes = need;
+  }
+  size_t len = 0;
+  const int rc = rt_hip_format_ppm_device(rgb_device, width, height, g.d_ppm_text, g.d_ppm_text_bytes, &len, g.stream);
+  if (rc != RT_OK) return rc;
+  if (bytes_out) *bytes_out = len;
+  if (len > capacity) return RT_ERR_TOO_LARGE;
+  if (len) HIP_TRY(hipMemcpyAsync(text_host, g.d_ppm_text, len, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return RT_OK;
+}
+
+int rt_hip_render_ppm(const rt_render_params* p, char* text_host, size_t capacity, size_t* bytes_out, rt_stats* stats) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  if (p->n_ranks != 1) return RT_ERR_INVALID; /* the file is one whole frame */
+  const size_t bytes = (size_t)g.scene.vsize * g.scene.hsize * 3;
+  if (bytes > g.d_rgb_bytes) {
+    if (g.d_rgb) (void)hipFree(g.d_rgb);
+    g.d_rgb = nullptr;
+    g.d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_rgb, bytes ? bytes : 16));
+    g.d_rgb_bytes = bytes;
+  }
+  rc = render_common(p, g.d_rgb, nullptr, g.stream, stats);
+  if (rc != RT_OK) return rc;
+  return rt_hip_format_ppm(g.d_rgb, g.scene.hsize, g.scene.vsize, text_host, capacity, bytes_out);
+}
+
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank) {
   if (vsize < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return RT_ERR_INVALID;
   if (n_ranks == 1) return vsize;
@@ -665,6 +780,10 @@ void rt_hip_shutdown(void) {
   if (g.d_tile_list) (void)hipFree(g.d_tile_list);
   if (g.d_rgb) (void)hipFree(g.d_rgb);
   if (g.d_canvas) (void)hipFree(g.d_canvas);
+  if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
+  if (g.d_ppm_off) (void)hipFree(g.d_ppm_off);
+  if (g.d_ppm_text) (void)hipFree(g.d_ppm_text);
+  if (g.h_ppm_total) (void)hipHostFree(g.h_ppm_total);
   if (g.ev0) (void)hipEventDestroy(g.ev0);
   if (g.ev1) (void)hipEventDestroy(g.ev1);
   if (g.tm0) (void)hipEventDestroy(g.tm0);

@@ -4,10 +4,12 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
+ *                 [--host-ppm]
  *
  * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres.
  * With no options it does what the reference binary does: lighthouse, 300x300, ./canvas.ppm,
- * reading ./lighthouse.obj.
+ * reading ./lighthouse.obj.  The P3 text of the file is formatted on the GPU (rt_hip_render_ppm) unless
+ * --host-ppm asks for the C writer rt_write_ppm; both emit the bytes of write_canvas_to_file (:1333).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,7 +35,7 @@ int main(int argc, char** argv) {
   const char* obj = "lighthouse.obj";
   const char* tris_f32 = NULL;
   const char* out = "canvas.ppm";
-  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
+  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
   double tri_refl = 0.0, sph_refl = 0.0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--brute")) accel = RT_ACCEL_BRUTE;
     else if (!strcmp(argv[i], "--bvh")) accel = RT_ACCEL_BVH;
+    else if (!strcmp(argv[i], "--host-ppm")) host_ppm = 1;
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -78,13 +81,19 @@ int main(int argc, char** argv) {
   if ((rc = rt_hip_init(device)) != RT_OK) return fail("rt_hip_init", rc);
   if ((rc = rt_hip_upload_scene(&s)) != RT_OK) return fail("rt_hip_upload_scene", rc);
 
-  uint8_t* rgb = malloc((size_t)W * H * 3);
-  if (!rgb) return 1;
+  const size_t cap = host_ppm ? (size_t)W * H * 3 : rt_hip_ppm_capacity(W, H);
+  uint8_t* buf = malloc(cap ? cap : 1); /* the 8-bit image, or the text of the file */
+  if (!buf) return 1;
+  size_t text_len = 0;
   rt_render_params p = {5 /* RECURSION_DEPTH */, G, accel, 1, 1, 1, 0, 0};
   rt_stats st;
   printf("Starting Render Process\n");
   double t0 = now_s();
-  if ((rc = rt_hip_render(&p, rgb, &st)) != RT_OK) return fail("rt_hip_render", rc);
+  if (host_ppm) {
+    if ((rc = rt_hip_render(&p, buf, &st)) != RT_OK) return fail("rt_hip_render", rc);
+  } else {
+    if ((rc = rt_hip_render_ppm(&p, (char*)buf, cap, &text_len, &st)) != RT_OK) return fail("rt_hip_render_ppm", rc);
+  }
   double dt = now_s() - t0;
   printf("\nRender Took %f Seconds\n", dt);
   unsigned long long rays = st.rays_primary + st.rays_shadow + st.rays_secondary;
@@ -93,8 +102,13 @@ int main(int argc, char** argv) {
          (unsigned long long)st.rays_secondary, st.kernel_ms, rays / (st.kernel_ms * 1e3),
          st.accel_used == RT_ACCEL_BVH ? "BVH" : "brute force");
   printf("Writing Canvas To File\n");
-  if ((rc = rt_write_ppm(out, rgb, W, H)) != RT_OK) return fail("rt_write_ppm", rc);
-  free(rgb);
+  if (host_ppm) {
+    if ((rc = rt_write_ppm(out, buf, W, H)) != RT_OK) return fail("rt_write_ppm", rc);
+  } else {
+    FILE* f = fopen(out, "wb");
+    if (!f || fwrite(buf, 1, text_len, f) != text_len || fclose(f) != 0) { perror(out); return 1; }
+  }
+  free(buf);
   rt_hip_shutdown();
   rt_scene_destroy(b);
   return 0;

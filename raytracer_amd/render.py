@@ -79,6 +79,43 @@ class HipRenderer:
             "rt_hip_render_device",
         )
 
+    # ---- write_canvas_to_file's P3 text (RayTracer.c:1333-1348), formatted on the device ----
+    def ppm_capacity(self, width, height):
+        return int(self._L.rt_hip_ppm_capacity(width, height))
+
+    def format_ppm_device(self, rgb_ptr, width, height, text_ptr, capacity, stream=None, wait=True):
+        """Text of the image at device address rgb_ptr into device memory at text_ptr; returns its length
+        (None with wait=False: ask ppm_last_length() later)."""
+        n = C.c_size_t(0)
+        _check(self._L.rt_hip_format_ppm_device(C.c_void_p(rgb_ptr), width, height, C.c_void_p(text_ptr), capacity,
+                                                C.byref(n) if wait else None, C.c_void_p(stream or 0)),
+               "rt_hip_format_ppm_device")
+        return int(n.value) if wait else None
+
+    def ppm_last_length(self):
+        n = C.c_size_t(0)
+        _check(self._L.rt_hip_ppm_last_length(C.byref(n)), "rt_hip_ppm_last_length")
+        return int(n.value)
+
+    def format_ppm(self, rgb_ptr, width, height):
+        """bytes of canvas.ppm for the 8-bit image at device address rgb_ptr."""
+        cap = self.ppm_capacity(width, height)
+        buf = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        _check(self._L.rt_hip_format_ppm(C.c_void_p(rgb_ptr), width, height, buf.ctypes.data, cap, C.byref(n)),
+               "rt_hip_format_ppm")
+        return buf[: n.value].tobytes()
+
+    def render_ppm(self, params=None, **kw):
+        """render + format on the device: (bytes of canvas.ppm, stats)."""
+        p = params or make_params(**kw)
+        cap = self.ppm_capacity(self.width, self.height)
+        buf = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        st = Stats()
+        _check(self._L.rt_hip_render_ppm(C.byref(p), buf.ctypes.data, cap, C.byref(n), C.byref(st)), "rt_hip_render_ppm")
+        return buf[: n.value].tobytes(), st
+
     def timer_start(self, stream=None):
         _check(self._L.rt_hip_event_record(0, C.c_void_p(stream or 0)), "rt_hip_event_record")
 
