@@ -204,3 +204,58 @@ def test_config5_cube_spheres_8k_16spp(hip):
         out[R.rank_row_map(H, 16, 8, rank)] = part
     assert np.array_equal(out, full)
     print(f"config 5: {st.rays} rays, kernel {st.kernel_ms:.2f} ms = {st.rays / st.kernel_ms / 1e3:.0f} Mrays/s")
+
+
+def icosphere(level):
+    """Unit sphere as 20 * 4^level triangles with single-precision vertices (what an OBJ loader delivers)."""
+    t = (1 + 5 ** 0.5) / 2
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11],
+                  [6, 2, 10], [8, 6, 7], [9, 8, 1]])
+    tri = v[f]
+    for _ in range(level):
+        a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+        ab, bc, ca = a + b, b + c, c + a
+        for m in (ab, bc, ca):
+            m /= np.linalg.norm(m, axis=1)[:, None]
+        tri = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1),
+                              np.stack([ab, bc, ca], 1)])
+    return tri.astype(np.float32).reshape(-1, 9)
+
+
+def mesh_scene(tris, w, h, reflective=0.0):
+    from raytracer_amd.scene import SceneBuilder
+
+    b = SceneBuilder()
+    b.set_camera(w, h, 0.7, (0.3, 1.2, -4.0), (0, 0, 0))
+    b.set_light((-4.0, 6.0, -5.0), (1, 1, 1))
+    b.add_triangles_f32(tris)
+    if reflective:
+        b.set_reflective(reflective, 0.0)
+    return b.finish(4)
+
+
+def test_large_mesh_81920_triangles_matches_oracle(hip):
+    """A mesh 60x the lighthouse: BVH nodes no longer fit the LDS staging, the walk reads them from memory."""
+    s = mesh_scene(icosphere(6), 64, 48, reflective=0.25)
+    assert s.n_tris == 81920 and s.n_bvh_nodes > 768
+    hip.upload(s)
+    got, st = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    want, ost = O.render_rgb(s)
+    assert O.probe().list_overflow == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary)
+    assert_image_parity(got, want, "icosphere 81920")
+
+
+def test_mesh_of_1_3_million_triangles_bvh_equals_exhaustive(hip):
+    s = mesh_scene(icosphere(8), 96, 64)
+    assert s.n_tris == 1310720
+    hip.upload(s)
+    a, sa = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    b, sb = hip.render(accel=R._ffi.RT_ACCEL_BRUTE, count_rays=True)
+    assert np.array_equal(a, b)
+    assert sa.rays == sb.rays and sa.prim_tests < sb.prim_tests / 1000
+    assert a.max() > 0
