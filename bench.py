@@ -117,6 +117,30 @@ def ppm_measurements(hip, dev, steps=50):
     return out
 
 
+def cpu_baseline_row_split(ref, rays_expected, cores=None):
+    """The same reference build as `cores` worker processes, each rendering row bands of the frame (the reference
+    itself has no threads: this is what a user gets from running it once per band).  Wall time of the whole job."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cores = cores or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    n_bands = cores * 4  # several bands per worker: the lit rows are not spread evenly
+    edges = [HEIGHT * i // n_bands for i in range(n_bands + 1)]
+
+    def band(i):
+        out = subprocess.run([ref, "--scene", SCENE, "--size", str(WIDTH), str(HEIGHT), "--rows", str(edges[i]),
+                              str(edges[i + 1])], capture_output=True, text=True, timeout=600)
+        return out.returncode
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        codes = list(pool.map(band, range(n_bands)))
+    dt = time.perf_counter() - t0
+    if any(codes):
+        return None
+    return {"value": round(rays_expected / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "seconds": round(dt, 3),
+            "sample": f"same frame as {n_bands} row bands over {cores} processes (includes process start-up)"}
+
+
 def cpu_baseline(rays_expected):
     """The reference (or, failing that, the CPU port) on the same frame, one core of this host."""
     ref = os.path.join(ROOT, "oracle", "_ref", "rt_ref_harness_timing")
@@ -125,10 +149,12 @@ def cpu_baseline(rays_expected):
                              text=True, timeout=600)
         if out.returncode == 0:
             info = json.loads(out.stdout.strip().splitlines()[-1])
-            return {"value": round(rays_expected / info["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                    "kind": "reference", "seconds": round(info["seconds"], 3),
-                    "sample": f"whole workload: {SCENE} {WIDTH}x{HEIGHT}, {rays_expected} rays, gcc -O2 build of the "
-                              "unmodified reference source"}
+            res = {"value": round(rays_expected / info["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                   "kind": "reference", "seconds": round(info["seconds"], 3),
+                   "sample": f"whole workload: {SCENE} {WIDTH}x{HEIGHT}, {rays_expected} rays, gcc -O2 build of the "
+                             "unmodified reference source (the reference is single-threaded)"}
+            res["row_split_processes"] = cpu_baseline_row_split(ref, rays_expected)
+            return res
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 

@@ -29,6 +29,7 @@ struct Context {
   int light_per_block = 4; /* background-only tiles per workgroup */
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
+  bool lds_stack = true;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
   hipEvent_t tm0 = nullptr, tm1 = nullptr; /* caller-driven timer */
@@ -111,6 +112,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
+constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT, int KIND>
@@ -121,6 +123,9 @@ void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderA
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, (const DevSphere*)g.d_spheres,
                        (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list,
                        rgb, canvas, g.d_counters);
+  else if (BVH && stage == 3)
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 3 : 0, KIND>), grid, block, lds, s, g.d_scene,
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else if (BVH)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
                        (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
@@ -162,6 +167,13 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
     } else if (bvh && g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
       stage = 2;
       lds = (size_t)g.scene.n_bvh_nodes * sizeof(DevBvh2);
+      /* the traversal stacks too, while two workgroups still fit a CU's 160 KiB (the walk's register budget
+       * allows no more than two anyway) */
+      const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)g.scene.bvh_depth;
+      if (g.lds_stack && g.scene.bvh_depth >= 1 && lds + stacks <= kMaxLdsPerWorkgroup) {
+        stage = 3;
+        lds += stacks;
+      }
     }
   }
   if (count) {
@@ -365,6 +377,7 @@ int rt_hip_init(int device) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("RT_HIP_LDS_STACK")) g.lds_stack = atoi(e) != 0; /* tuning knob: 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS")) g.use_lds = atoi(e) != 0; /* tuning knob: 0 = read primitives from global memory */
   if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) { /* tuning knob */
     const int v = atoi(e);

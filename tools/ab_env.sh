@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab_env.sh VAR "<values>" "<scenes>" [lib tag]
+# usage: tools/ab_env.sh "<VAR=a VAR=b ...>" "<scenes>"  -- same box, same library, one environment setting per run
 for rep in 1 2; do
-for v in $2; do echo "== $1=$v (rep $rep)"; env $1=$v RT_HIP_LIB=$4 timeout -k 10 120 python -u tools/ablate.py $3 2>&1 | grep -E "full" ; done
+for e in $1; do echo "== $e (rep $rep)"; env $e timeout -k 10 120 python -u tools/ablate.py $2 2>&1 | grep -E "full" ; done
 done
