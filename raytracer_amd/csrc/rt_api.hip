@@ -121,17 +121,17 @@ void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderA
   const dim3 block(RT_TILE_W * RT_TILE_H);
   if (stage == 0)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, (const DevSphere*)g.d_spheres,
-                       (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list,
+                       (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list,
                        rgb, canvas, g.d_counters);
   else if (BVH && stage == 3)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 3 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else if (BVH)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, a, g.launch_tile_list, rgb, canvas, g.d_counters);
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
 }
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
 void launch_kind(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
@@ -567,8 +567,6 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   }
   for (int c = 0; c < 3; ++c) { g.mesh_lo[c] = blo[c] - pad; g.mesh_hi[c] = bhi[c] + pad; }
   g.scene_serial++;
-  d.tri_primary = (const DevTriPrimary*)g.d_tri_primary;
-  d.sph_primary = (const DevSpherePrimary*)g.d_sph_primary;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
   memcpy(d.light_int, sc->light.intensity, sizeof d.light_int);
   d.hsize = sc->camera.hsize;
@@ -577,11 +575,6 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   d.n_tris = nt;
   d.n_bvh_nodes = use_bvh ? n_bvh_inner : 0;
   d.bvh_depth = depth;
-  d.spheres = (const DevSphere*)g.d_spheres;
-  d.tris = (const DevTri*)g.d_tris;
-  d.tri_normals = (const double*)g.d_normals;
-  d.materials = (const rt_material*)g.d_materials;
-  d.bvh = (const DevBvh2*)g.d_bvh;
   g.host_camera = sc->camera;
   g.reflective = false;
   for (int i = 0; i < sc->n_materials; ++i)
