@@ -38,15 +38,15 @@ typedef enum rt_status {
   RT_ERR_INVALID = -1,     /* NULL / out-of-range argument                      */
   RT_ERR_NO_DEVICE = -2,   /* no HIP device, or ordinal out of range             */
   RT_ERR_HIP = -3,         /* a HIP runtime call failed (see rt_hip_last_error)  */
-  RT_ERR_UNSUPPORTED = -4, /* scene uses something outside the path (non-affine
-                              transform, pattern, transparency, ...)            */
+  RT_ERR_UNSUPPORTED = -4, /* scene uses something outside the path (e.g. a
+                              non-affine or singular transform)                  */
   RT_ERR_NOT_READY = -5,   /* init / upload_scene has not been called            */
   RT_ERR_TOO_LARGE = -6    /* scene or image exceeds a documented limit          */
 } rt_status;
 
-/* Subset of `material` (RayTracer.c:57) that lighting() (RayTracer.c:1273) and
+/* The part of `material` (RayTracer.c:57) that lighting() (RayTracer.c:1273) and
  * reflected_color() (RayTracer.c:1443) read when has_pattern == false and
- * transparency == 0. */
+ * transparency == 0; rt_material_ext below holds the rest. */
 typedef struct rt_material {
   double color[3];
   double ambient;
@@ -55,6 +55,41 @@ typedef struct rt_material {
   double shininess;
   double reflective;
 } rt_material;
+
+/* The rest of `material` (RayTracer.c:57), one entry per rt_material, for worlds that use patterns or
+ * transparency: refracted_color/schlick (RayTracer.c:1453-1483) read transparency and refractive_index,
+ * lighting() -> stripe_at_object -> pattern_at (RayTracer.c:1276, 1259, 1166) read the pattern.  The caller
+ * supplies inverse(pattern.transform), which stripe_at_object recomputes per call (RayTracer.c:1267). */
+enum {
+  RT_PATTERN_NONE = -1,    /* has_pattern == false */
+  RT_PATTERN_TEST = 0,     /* enum pattern_type, RayTracer.c:53 */
+  RT_PATTERN_STRIPE = 1,
+  RT_PATTERN_GRADIENT = 2,
+  RT_PATTERN_RING = 3,
+  RT_PATTERN_CHECKER = 4
+};
+typedef struct rt_material_ext {
+  double transparency;
+  double refractive_index;
+  double pattern_from[3];
+  double pattern_to[3];
+  double pattern_inv[16];
+  int32_t pattern_type;
+  int32_t reserved;
+} rt_material_ext;
+
+/* A plane, cube or cylinder of the world list (RayTracer.c:69-89; intersected by the PLANE / CUBE / CYLINDER
+ * branches of intersect_all_but_triangle, RayTracer.c:904-918).  `type` holds the reference's enum value. */
+enum { RT_SHAPE_PLANE = 0, RT_SHAPE_CUBE = 3, RT_SHAPE_CYLINDER = 4 };
+typedef struct rt_shape {
+  double inv[16];    /* inverse(transform), row-major                         */
+  double minimum;    /* cylinder: shape.minimum / maximum / closed            */
+  double maximum;
+  int32_t type;
+  int32_t closed;
+  int32_t material;  /* index into materials                                  */
+  int32_t order;     /* position in the world list                            */
+} rt_shape;
 
 /* `camera` (RayTracer.c:96) with the loop-invariant inverse(view_transform)
  * that ray_for_pixel recomputes twice per pixel (RayTracer.c:1553,1562)
@@ -118,6 +153,15 @@ typedef struct rt_scene {
   int32_t n_bvh_nodes;
   const rt_bvh_node* bvh_nodes;
   const int32_t* bvh_tri;       /* [n_tris] triangle indices in leaf order      */
+
+  /* ---- worlds beyond spheres and triangles (all optional: 0 / NULL) ---- */
+  int32_t n_shapes;                     /* planes, cubes, cylinders                       */
+  const rt_shape* shapes;
+  const rt_material_ext* materials_ext; /* [n_materials] or NULL: no pattern, no transparency */
+  /* inverse(transform) of the FIRST object of the world list: shade_hit hands w->objects, not the object
+   * that was hit, to lighting() as the shape whose transform places the pattern (RayTracer.c:1489, 1277,
+   * 1263).  Read only when a material has a pattern. */
+  double first_object_inv[16];
 } rt_scene;
 
 enum {

@@ -44,6 +44,9 @@ void rt_view_transform(const double from[3], const double to[3], const double up
 /* default material, create_material_default RayTracer.c:704 */
 rt_material rt_material_default(void);
 
+/* the pattern / transparency half of the default material (no pattern, opaque, refractive_index 1), :712-717 */
+rt_material_ext rt_material_ext_default(void);
+
 /* ---- scene builder ---- */
 typedef struct rt_scene_builder rt_scene_builder;
 
@@ -60,6 +63,15 @@ int rt_scene_set_light(rt_scene_builder* b, const double position[3], const doub
 /* Append to the world list (add_shape_to_world, RayTracer.c:1078); the return
  * value is the position in the list (>= 0) or a negative rt_status. */
 int rt_scene_add_sphere(rt_scene_builder* b, const double transform[16], const rt_material* m);
+/* a sphere whose material has a pattern and/or transparency; pattern_transform (NULL = identity) is
+ * pattern.transform as set_pattern_transform stores it (RayTracer.c:1061), x->pattern_inv is ignored */
+int rt_scene_add_sphere_ext(rt_scene_builder* b, const double transform[16], const rt_material* m,
+                            const rt_material_ext* x, const double* pattern_transform);
+/* create_shape(PLANE | CUBE | CYLINDER) (RayTracer.c:968): type = RT_SHAPE_*; minimum / maximum / closed are the
+ * cylinder's fields (-INFINITY, INFINITY, 0 by default, :989-993) and ignored for the other types */
+int rt_scene_add_shape(rt_scene_builder* b, int type, const double transform[16], const rt_material* m,
+                       const rt_material_ext* x, const double* pattern_transform, double minimum, double maximum,
+                       int closed);
 int rt_scene_add_triangle(rt_scene_builder* b, const double p1[3], const double p2[3], const double p3[3],
                           const rt_material* m);
 /* n triangles, 9 floats each (p1 p2 p3), widened to double as load_model_file does (RayTracer.c:1657-1669) */
@@ -79,7 +91,10 @@ int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out);
 /* ---- the reference's stock scenes (RayTracer.c), any image size ---- */
 /* "spheres": render_complete_world :5848;  "cube": render_some_triangles :6727 with the teapot.h mesh;
  * "lighthouse": render_lighthouse_scene :6772 (camera + light only, add the mesh yourself);
- * "cube_spheres": the six spheres followed by the teapot.h mesh, spheres camera and light. */
+ * "cube_spheres": the six spheres followed by the teapot.h mesh, spheres camera and light;
+ * "refraction": render_refraction_scene :6491 (planes, checkers, spheres, mirror ball, cube, open cylinder);
+ * "world_with_plane": render_complete_world_with_plane :6227 (planes, patterns, glass sphere);
+ * "dual_spheres": render_dual_spheres_refracting_on_floor :6419 (nested glass spheres before a checkered wall). */
 int rt_scene_stock(rt_scene_builder* b, const char* name, int hsize, int vsize);
 
 /* ---- image output ---- */

@@ -16,6 +16,12 @@
  * array handed to qsort shows the list occupancy and exact-zero t values.
  *
  * Built only where the reference is present (oracle/Makefile -> oracle/_ref/).
+ *
+ * Second build, -DRT_REF_CAPTURE -fPIC -shared (librt_ref_capture.so): for the scene functions this file does
+ * not repeat (planes, patterns, glass, cube, cylinder) the REFERENCE'S OWN function builds the world.  Compiled
+ * position-independent, its call render(c, &w) goes through the PLT; the executable rt_ref_capture defines
+ * render() and hands the camera and world it receives to rt_capture_render() below, which runs the same
+ * per-pixel loop at the requested size with the reference's own field of view and view transform.
  */
 #include <stdint.h>
 #include <stdlib.h> /* before the macro below, so that only call sites are rewritten */
@@ -247,6 +253,24 @@ static void dump_scene(const char* path, scene_t* s) {
                      sp->material.reflective, sp->material.transparency, sp->material.refractive_index};
     put(f, mat, sizeof mat);
   }
+  /* second section: what planes, cubes, cylinders, patterns and glass add */
+  put(f, "RTEXT001", 8);
+  for (shape* sp = s->w.objects; sp; sp = sp->next) {
+    double mm[2] = {sp->type == CYLINDER ? sp->minimum : 0.0, sp->type == CYLINDER ? sp->maximum : 0.0};
+    put(f, mm, sizeof mm);
+    int32_t fl[4] = {sp->type == CYLINDER ? (int32_t)sp->closed : 0, (int32_t)sp->material.has_pattern,
+                     sp->material.has_pattern ? (int32_t)sp->material.pattern.type : -1, 0};
+    put(f, fl, sizeof fl);
+    tuple z = {0, 0, 0, 0};
+    put_tuple(f, sp->material.has_pattern ? sp->material.pattern.from : z);
+    put_tuple(f, sp->material.has_pattern ? sp->material.pattern.to : z);
+    Mat4x4 pt, pinv;
+    mat4x4_set_ident(pt);
+    if (sp->material.has_pattern) mat4x4_copy(sp->material.pattern.transform, pt);
+    put(f, pt, sizeof pt);
+    mat4x4_inverse(pt, pinv);
+    put(f, pinv, sizeof pinv);
+  }
   fclose(f);
 }
 
@@ -261,38 +285,159 @@ static void usage(void) {
   fprintf(stderr,
           "rt_ref_harness --scene lighthouse|cube|spheres|cube_spheres [--size W H] [--spp-grid G]\n"
           "   [--tri-reflective K] [--sph-reflective K] [--obj lighthouse.obj] [--rows Y0 Y1]\n"
-          "   [--stock] [--dump-scene F] [--out-f64 F] [--out-rgb F] [--out-ppm F] [--no-render]\n");
+          "   [--stock] [--dump-scene F] [--out-f64 F] [--out-rgb F] [--out-ppm F] [--no-render]\n"
+          "rt_ref_capture --capture --scene refraction|world_with_plane|dual_spheres|cube|spheres ... (same options)\n");
   exit(2);
 }
 
+/* options shared by main and the capture callback */
+static struct {
+  const char* scene;
+  const char *dump, *out_f64, *out_rgb, *out_ppm;
+  int W, H, G, no_render, y0, y1, stock;
+  double tri_refl, sph_refl;
+} g_opt;
+
+static void write_outputs(const double* img, int W, int H) {
+  if (img && g_opt.out_f64) {
+    FILE* f = fopen(g_opt.out_f64, "wb");
+    if (!f) { perror(g_opt.out_f64); exit(2); }
+    put(f, img, sizeof(double) * 3 * W * H);
+    fclose(f);
+  }
+  if (img && g_opt.out_rgb) {
+    FILE* f = fopen(g_opt.out_rgb, "wb");
+    if (!f) { perror(g_opt.out_rgb); exit(2); }
+    for (size_t k = 0; k < (size_t)3 * W * H; ++k) {
+      unsigned char b = (unsigned char)color_convert(img[k]);
+      put(f, &b, 1);
+    }
+    fclose(f);
+  }
+  if (img && g_opt.out_ppm) { /* same bytes as write_canvas_to_file, RayTracer.c:1333-1348 */
+    FILE* f = fopen(g_opt.out_ppm, "w");
+    if (!f) { perror(g_opt.out_ppm); exit(2); }
+    fprintf(f, "P3\n");
+    fprintf(f, "%d %d\n255\n", W, H);
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 0]));
+        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 1]));
+        fprintf(f, "%d \n", color_convert(img[(y * W + x) * 3 + 2]));
+      }
+    fclose(f);
+  }
+}
+
+static void report(double seconds) {
+  printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"rows\": [%d, %d], \"stock\": %d, "
+         "\"rays\": %llu, \"max_list\": %zu, \"exact_zero_t\": %llu, \"seconds\": %.6f}\n",
+         g_opt.scene, g_opt.W, g_opt.H, g_opt.G, g_opt.y0, g_opt.y1, g_opt.stock, (unsigned long long)g_rays, g_max_list,
+         (unsigned long long)g_zero_t, seconds);
+  fflush(stdout);
+}
+
+/* the per-pixel loop of render() (RayTracer.c:1576-1587) at any size and sub-pixel grid, then the outputs */
+static void trace_scene(scene_t* s) {
+  const int W = g_opt.W, H = g_opt.H, G = g_opt.G;
+  double* img = NULL;
+  double seconds = 0.0;
+  for (shape* sp = s->w.objects; sp; sp = sp->next) {
+    if (sp->type == TRIANGLE && g_opt.tri_refl != 0.0) sp->material.reflective = g_opt.tri_refl;
+    if (sp->type == SPHERE && g_opt.sph_refl != 0.0) sp->material.reflective = g_opt.sph_refl;
+  }
+  if (g_opt.dump) dump_scene(g_opt.dump, s);
+  if (g_opt.y1 < 0 || g_opt.y1 > H) g_opt.y1 = H;
+  if (!g_opt.no_render) {
+    img = calloc((size_t)3 * W * H, sizeof(double));
+    g_rays = 0;
+    g_zero_t = 0;
+    g_max_list = 0;
+    double t0 = now_s();
+    for (int y = g_opt.y0; y < g_opt.y1; ++y) {
+      for (int x = 0; x < W; ++x) {
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int j = 0; j < G; ++j) {
+          for (int i = 0; i < G; ++i) {
+            /* G == 1 gives px = x exactly: the reference's render() loop, RayTracer.c:1576-1587 */
+            double px = x + (i + 0.5) / G - 0.5;
+            double py = y + (j + 0.5) / G - 0.5;
+            ray r = ray_for_pixel(s->c, px, py);
+            tuple col = color_at(&s->w, &r, RECURSION_DEPTH);
+            sx += col.x; sy += col.y; sz += col.z;
+          }
+        }
+        double n = (double)(G * G);
+        img[(y * W + x) * 3 + 0] = sx / n;
+        img[(y * W + x) * 3 + 1] = sy / n;
+        img[(y * W + x) * 3 + 2] = sz / n;
+      }
+    }
+    seconds = now_s() - t0;
+  }
+  write_outputs(img, W, H);
+  report(seconds);
+  free(img);
+}
+
+#ifdef RT_REF_CAPTURE
+/* called by the executable's render(): the world is the one the reference's scene function just built */
+void rt_capture_render(camera* c, world* w) {
+  scene_t s;
+  s.w = *w;
+  s.c = create_camera(g_opt.W, g_opt.H, c->field_of_view);
+  mat4x4_copy(c->view_transform, s.c->view_transform);
+  trace_scene(&s);
+  free(s.c);
+}
+#endif
+
+#ifdef RT_REF_CAPTURE
+int rt_harness_main(int argc, char** argv) {
+#else
 int main(int argc, char** argv) {
-  const char* scene = NULL;
+#endif
   const char* obj = "lighthouse.obj";
-  const char *dump = NULL, *out_f64 = NULL, *out_rgb = NULL, *out_ppm = NULL;
-  int W = HORIZONTAL_SIZE, H = VERTICAL_SIZE, G = 1, stock = 0, no_render = 0, y0 = 0, y1 = -1;
-  double tri_refl = 0.0, sph_refl = 0.0;
+  memset(&g_opt, 0, sizeof g_opt);
+  g_opt.W = HORIZONTAL_SIZE; g_opt.H = VERTICAL_SIZE; g_opt.G = 1; g_opt.y1 = -1;
+  int capture = 0;
   for (int i = 1; i < argc; ++i) {
-    if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
-    else if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
-    else if (!strcmp(argv[i], "--spp-grid") && i + 1 < argc) G = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--tri-reflective") && i + 1 < argc) tri_refl = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--sph-reflective") && i + 1 < argc) sph_refl = atof(argv[++i]);
+    if (!strcmp(argv[i], "--scene") && i + 1 < argc) g_opt.scene = argv[++i];
+    else if (!strcmp(argv[i], "--size") && i + 2 < argc) { g_opt.W = atoi(argv[++i]); g_opt.H = atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "--spp-grid") && i + 1 < argc) g_opt.G = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--tri-reflective") && i + 1 < argc) g_opt.tri_refl = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--sph-reflective") && i + 1 < argc) g_opt.sph_refl = atof(argv[++i]);
     else if (!strcmp(argv[i], "--obj") && i + 1 < argc) obj = argv[++i];
-    else if (!strcmp(argv[i], "--rows") && i + 2 < argc) { y0 = atoi(argv[++i]); y1 = atoi(argv[++i]); }
-    else if (!strcmp(argv[i], "--stock")) stock = 1;
-    else if (!strcmp(argv[i], "--no-render")) no_render = 1;
-    else if (!strcmp(argv[i], "--dump-scene") && i + 1 < argc) dump = argv[++i];
-    else if (!strcmp(argv[i], "--out-f64") && i + 1 < argc) out_f64 = argv[++i];
-    else if (!strcmp(argv[i], "--out-rgb") && i + 1 < argc) out_rgb = argv[++i];
-    else if (!strcmp(argv[i], "--out-ppm") && i + 1 < argc) out_ppm = argv[++i];
+    else if (!strcmp(argv[i], "--rows") && i + 2 < argc) { g_opt.y0 = atoi(argv[++i]); g_opt.y1 = atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "--stock")) g_opt.stock = 1;
+    else if (!strcmp(argv[i], "--capture")) capture = 1;
+    else if (!strcmp(argv[i], "--no-render")) g_opt.no_render = 1;
+    else if (!strcmp(argv[i], "--dump-scene") && i + 1 < argc) g_opt.dump = argv[++i];
+    else if (!strcmp(argv[i], "--out-f64") && i + 1 < argc) g_opt.out_f64 = argv[++i];
+    else if (!strcmp(argv[i], "--out-rgb") && i + 1 < argc) g_opt.out_rgb = argv[++i];
+    else if (!strcmp(argv[i], "--out-ppm") && i + 1 < argc) g_opt.out_ppm = argv[++i];
     else usage();
   }
+  const char* scene = g_opt.scene;
+  const int W = g_opt.W, H = g_opt.H, G = g_opt.G;
   if (!scene || W < 1 || H < 1 || G < 1) usage();
   contents = containers_create(); /* RayTracer.c:7048 */
 
-  double* img = NULL; /* [H][W][3] */
-  double seconds = 0.0;
-  if (stock) {
+  if (capture) {
+#ifdef RT_REF_CAPTURE
+    /* the reference's own scene function; its render() call lands in rt_capture_render */
+    if (!strcmp(scene, "refraction")) render_refraction_scene();
+    else if (!strcmp(scene, "world_with_plane")) render_complete_world_with_plane();
+    else if (!strcmp(scene, "dual_spheres")) render_dual_spheres_refracting_on_floor();
+    else if (!strcmp(scene, "cube")) render_some_triangles();
+    else if (!strcmp(scene, "spheres")) render_complete_world();
+    else usage();
+    return 0;
+#else
+    usage();
+#endif
+  }
+  if (g_opt.stock) {
     /* the reference's own scene function and its own render() into `canvas` */
     if (W != HORIZONTAL_SIZE || H != VERTICAL_SIZE || G != 1) usage();
     if (!strcmp(scene, "lighthouse")) {
@@ -307,86 +452,30 @@ int main(int argc, char** argv) {
     if (!strcmp(scene, "lighthouse")) render_lighthouse_scene();
     else if (!strcmp(scene, "cube")) render_some_triangles();
     else if (!strcmp(scene, "spheres")) render_complete_world();
+    else if (!strcmp(scene, "refraction")) render_refraction_scene();
+    else if (!strcmp(scene, "world_with_plane")) render_complete_world_with_plane();
+    else if (!strcmp(scene, "dual_spheres")) render_dual_spheres_refracting_on_floor();
     else usage();
-    seconds = now_s() - t0;
-    img = malloc(sizeof(double) * 3 * W * H);
+    double seconds = now_s() - t0;
+    double* img = malloc(sizeof(double) * 3 * W * H);
     for (int y = 0; y < H; ++y)
       for (int x = 0; x < W; ++x) {
         img[(y * W + x) * 3 + 0] = canvas[x][y].x;
         img[(y * W + x) * 3 + 1] = canvas[x][y].y;
         img[(y * W + x) * 3 + 2] = canvas[x][y].z;
       }
-    y0 = 0; y1 = H;
-  } else {
-    scene_t s;
-    if (!strcmp(scene, "lighthouse")) s = scene_lighthouse(W, H, obj);
-    else if (!strcmp(scene, "cube")) s = scene_cube(W, H);
-    else if (!strcmp(scene, "spheres")) s = scene_spheres(W, H);
-    else if (!strcmp(scene, "cube_spheres")) s = scene_cube_spheres(W, H);
-    else usage();
-    for (shape* sp = s.w.objects; sp; sp = sp->next) {
-      if (sp->type == TRIANGLE && tri_refl != 0.0) sp->material.reflective = tri_refl;
-      if (sp->type == SPHERE && sph_refl != 0.0) sp->material.reflective = sph_refl;
-    }
-    if (dump) dump_scene(dump, &s);
-    if (y1 < 0 || y1 > H) y1 = H;
-    if (!no_render) {
-      img = calloc((size_t)3 * W * H, sizeof(double));
-      g_rays = 0;
-      double t0 = now_s();
-      for (int y = y0; y < y1; ++y) {
-        for (int x = 0; x < W; ++x) {
-          double sx = 0.0, sy = 0.0, sz = 0.0;
-          for (int j = 0; j < G; ++j) {
-            for (int i = 0; i < G; ++i) {
-              /* G == 1 gives px = x exactly: the reference's render() loop, RayTracer.c:1576-1587 */
-              double px = x + (i + 0.5) / G - 0.5;
-              double py = y + (j + 0.5) / G - 0.5;
-              ray r = ray_for_pixel(s.c, px, py);
-              tuple col = color_at(&s.w, &r, RECURSION_DEPTH);
-              sx += col.x; sy += col.y; sz += col.z;
-            }
-          }
-          double n = (double)(G * G);
-          img[(y * W + x) * 3 + 0] = sx / n;
-          img[(y * W + x) * 3 + 1] = sy / n;
-          img[(y * W + x) * 3 + 2] = sz / n;
-        }
-      }
-      seconds = now_s() - t0;
-    }
+    g_opt.y0 = 0; g_opt.y1 = H;
+    write_outputs(img, W, H);
+    report(seconds);
+    free(img);
+    return 0;
   }
-
-  if (img && out_f64) {
-    FILE* f = fopen(out_f64, "wb");
-    if (!f) { perror(out_f64); return 2; }
-    put(f, img, sizeof(double) * 3 * W * H);
-    fclose(f);
-  }
-  if (img && out_rgb) {
-    FILE* f = fopen(out_rgb, "wb");
-    if (!f) { perror(out_rgb); return 2; }
-    for (size_t k = 0; k < (size_t)3 * W * H; ++k) {
-      unsigned char b = (unsigned char)color_convert(img[k]);
-      put(f, &b, 1);
-    }
-    fclose(f);
-  }
-  if (img && out_ppm) { /* same bytes as write_canvas_to_file, RayTracer.c:1333-1348 */
-    FILE* f = fopen(out_ppm, "w");
-    if (!f) { perror(out_ppm); return 2; }
-    fprintf(f, "P3\n");
-    fprintf(f, "%d %d\n255\n", W, H);
-    for (int y = 0; y < H; ++y)
-      for (int x = 0; x < W; ++x) {
-        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 0]));
-        fprintf(f, "%d ", color_convert(img[(y * W + x) * 3 + 1]));
-        fprintf(f, "%d \n", color_convert(img[(y * W + x) * 3 + 2]));
-      }
-    fclose(f);
-  }
-  printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"rows\": [%d, %d], \"stock\": %d, "
-         "\"rays\": %llu, \"max_list\": %zu, \"exact_zero_t\": %llu, \"seconds\": %.6f}\n",
-         scene, W, H, G, y0, y1, stock, (unsigned long long)g_rays, g_max_list, (unsigned long long)g_zero_t, seconds);
+  scene_t s;
+  if (!strcmp(scene, "lighthouse")) s = scene_lighthouse(W, H, obj);
+  else if (!strcmp(scene, "cube")) s = scene_cube(W, H);
+  else if (!strcmp(scene, "spheres")) s = scene_spheres(W, H);
+  else if (!strcmp(scene, "cube_spheres")) s = scene_cube_spheres(W, H);
+  else usage();
+  trace_scene(&s);
   return 0;
 }

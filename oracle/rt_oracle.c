@@ -7,12 +7,11 @@
  * reference binary is plain x86-64 SSE2 code.
  *
  * Deliberate differences from the reference, none of which changes a value:
- *   - inverse(transform) and inverse(view_transform) arrive precomputed (the
- *     reference recomputes them per ray: lines 900, 724, 1553, 1562);
- *   - the refraction bookkeeping of prepare_computations (lines 1378-1406) is
- *     left out: with transparency == 0 refracted_color returns point(0,0,0)
- *     whatever n1/n2 hold (line 1457);
- *   - patterns, planes, cubes and cylinders are not handled.
+ *   - inverse(transform), inverse(pattern.transform) and inverse(view_transform)
+ *     arrive precomputed (the reference recomputes them per ray: lines 900,
+ *     724, 1263, 1267, 1553, 1562);
+ *   - the container list of prepare_computations (lines 1378-1406) holds
+ *     world-list positions instead of shape pointers.
  */
 #include "rt_oracle.h"
 
@@ -78,7 +77,6 @@ static void list_init(isect_list* l) { /* line 112 */
 }
 static int list_add(isect_list* l, double t, long id) { /* line 159 */
   if (l->count == RTO_LIST_SIZE) { ++g_probe.list_overflow; return 0; }
-  if (t == 0.0) ++g_probe.exact_zero_t;
   int i = 0;
   /* a slot counts as used only while its t is neither 0.0 nor DBL_MIN (line 168) */
   while (i < RTO_LIST_SIZE - 1 && l->e[i].t != 0.0 && l->e[i].t != DBL_MIN) ++i;
@@ -95,6 +93,7 @@ static int isect_cmp(const void* a, const void* b) { /* line 131 */
 }
 static void list_sort(isect_list* l) { /* line 139: same libc qsort as the reference */
   if ((uint64_t)l->count > g_probe.max_list) g_probe.max_list = (uint64_t)l->count;
+  for (int i = 0; i < l->count; ++i) if (l->e[i].t == 0.0) ++g_probe.exact_zero_t; /* as the harness probe counts them */
   qsort(l->e, (size_t)l->count, sizeof(isect_t), isect_cmp);
 }
 static const isect_t* list_hit(const isect_list* l) { /* line 143 */
@@ -110,7 +109,7 @@ static const isect_t* list_hit(const isect_list* l) { /* line 143 */
 }
 
 /* ---- world in list order ---- */
-typedef struct { int kind; int idx; } prim_ref; /* kind 0 sphere, 1 triangle */
+typedef struct { int kind; int idx; } prim_ref; /* kind 0 sphere, 1 triangle, 2 plane / cube / cylinder */
 typedef struct {
   const rt_scene* s;
   int n;
@@ -120,7 +119,7 @@ typedef struct {
 
 static int world_open(world_t* w, const rt_scene* s) {
   w->s = s;
-  w->n = s->n_spheres + s->n_tris;
+  w->n = s->n_spheres + s->n_tris + s->n_shapes;
   w->rays_shadow = w->rays_secondary = 0;
   w->order = malloc(sizeof(prim_ref) * (size_t)(w->n > 0 ? w->n : 1));
   if (!w->order) return RT_ERR_INVALID;
@@ -134,6 +133,11 @@ static int world_open(world_t* w, const rt_scene* s) {
     int k = s->tri_order[i];
     if (k < 0 || k >= w->n || w->order[k].kind != -1) { free(w->order); return RT_ERR_INVALID; }
     w->order[k].kind = 1; w->order[k].idx = i;
+  }
+  for (int i = 0; i < s->n_shapes; ++i) {
+    int k = s->shapes[i].order;
+    if (k < 0 || k >= w->n || w->order[k].kind != -1) { free(w->order); return RT_ERR_INVALID; }
+    w->order[k].kind = 2; w->order[k].idx = i;
   }
   return RT_OK;
 }
@@ -178,6 +182,92 @@ static int isect_triangle_t(v4 p1, v4 e1, v4 e2, const ray_t* r, double* t_out) 
   return 1;
 }
 
+/* ---- plane / cube / cylinder branches of intersect_all_but_triangle, lines 898-918 ---- */
+static double max3(double a, double b, double c) { /* line 687 */
+  double m = a;
+  if (b > m) m = b;
+  if (c > m) m = c;
+  return m;
+}
+static double min3(double a, double b, double c) { /* line 695 */
+  double m = a;
+  if (b < m) m = b;
+  if (c < m) m = c;
+  return m;
+}
+static void check_axis(double origin, double direction, double* tmin_out, double* tmax_out) { /* line 799 */
+  double tmin_numerator = -1 - origin;
+  double tmax_numerator = 1 - origin;
+  double tmin, tmax;
+  if (fabs(direction) >= DBL_EPSILON) {
+    tmin = tmin_numerator / direction;
+    tmax = tmax_numerator / direction;
+  } else {
+    tmin = tmin_numerator * INFINITY;
+    tmax = tmax_numerator * INFINITY;
+  }
+  if (tmin > tmax) { double tt = tmin; tmin = tmax; tmax = tt; }
+  *tmin_out = tmin;
+  *tmax_out = tmax;
+}
+static void isect_cube(const ray_t* r, isect_list* l, long id) { /* line 826 */
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  check_axis(r->origin.x, r->direction.x, &xmin, &xmax);
+  check_axis(r->origin.y, r->direction.y, &ymin, &ymax);
+  check_axis(r->origin.z, r->direction.z, &zmin, &zmax);
+  double tmin = max3(xmin, ymin, zmin);
+  double tmax = min3(xmax, ymax, zmax);
+  if (tmin >= tmax) return;
+  if (tmax < 0) return;
+  list_add(l, tmin, id);
+  list_add(l, tmax, id);
+}
+static int check_cap(const ray_t* r, double t) { /* line 842 */
+  double x = r->origin.x + t * r->direction.x;
+  double z = r->origin.z + t * r->direction.z;
+  return x * x + z * z <= 1;
+}
+static void isect_cylinder(const rt_shape* sp, const ray_t* r, isect_list* l, long id) { /* lines 863-890, 849-861 */
+  double a = r->direction.x * r->direction.x + r->direction.z * r->direction.z;
+  if ((!a) < RTO_EPSILON) { /* as written in the reference: true whenever a != 0 */
+    double b = 2.0 * r->origin.x * r->direction.x + 2.0 * r->origin.z * r->direction.z;
+    double c = r->origin.x * r->origin.x + r->origin.z * r->origin.z - 1.0;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0) return;
+    double t0 = (-b - (sqrt(disc))) / (2 * a);
+    double t1 = (-b + (sqrt(disc))) / (2 * a);
+    if (t0 > t1) { double tt = t0; t0 = t1; t1 = tt; }
+    double y0 = r->origin.y + t0 * r->direction.y;
+    if (sp->minimum < y0 && y0 < sp->maximum) list_add(l, t0, id);
+    double y1 = r->origin.y + t1 * r->direction.y;
+    if (sp->minimum < y1 && y1 < sp->maximum) list_add(l, t1, id);
+  }
+  if (!sp->closed) return; /* intersect_caps */
+  double t = (sp->minimum - r->origin.y) / r->direction.y;
+  if (check_cap(r, t)) list_add(l, t, id);
+  t = (sp->maximum - r->origin.y) / r->direction.y;
+  if (check_cap(r, t)) list_add(l, t, id);
+}
+static void isect_shape(const rt_shape* sp, const ray_t* r, isect_list* l, long id) {
+  ray_t r2; /* transform(), line 792 */
+  r2.origin = mat_mul_v4(sp->inv, r->origin);
+  r2.direction = mat_mul_v4(sp->inv, r->direction);
+  switch (sp->type) {
+    case RT_SHAPE_PLANE: /* lines 904-912 */
+      if (fabs(r2.direction.y) < RTO_EPSILON) return;
+      list_add(l, (-r2.origin.y) / r2.direction.y, id);
+      return;
+    case RT_SHAPE_CUBE:
+      isect_cube(&r2, l, id);
+      return;
+    case RT_SHAPE_CYLINDER:
+      isect_cylinder(sp, &r2, l, id);
+      return;
+    default:
+      return;
+  }
+}
+
 /* ---- intersect_world, lines 1043-1055 ---- */
 static void isect_world(const world_t* w, const ray_t* r, isect_list* l) {
   const rt_scene* s = w->s;
@@ -185,6 +275,8 @@ static void isect_world(const world_t* w, const ray_t* r, isect_list* l) {
     prim_ref p = w->order[k];
     if (p.kind == 0) {
       isect_sphere(s->sph_inv + 16 * (size_t)p.idx, r, l, k);
+    } else if (p.kind == 2) {
+      isect_shape(&s->shapes[p.idx], r, l, k);
     } else {
       double t;
       if (isect_triangle_t(tri_row(s, p.idx, 0, 1.0), tri_row(s, p.idx, 3, 0.0), tri_row(s, p.idx, 6, 0.0), r, &t))
@@ -204,24 +296,79 @@ static v4 normal_at_sphere(const double inv[16], v4 point) {
   world_normal.w = 0.0;
   return v4_normalize(world_normal);
 }
+static v4 normal_at_shape(const rt_shape* sp, v4 point) {
+  if (sp->type == RT_SHAPE_PLANE) { /* normal_at_shape_sphere_plane, lines 721-749 */
+    double tr[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) tr[i * 4 + j] = sp->inv[j * 4 + i];
+    v4 world_normal = mat_mul_v4(tr, v4_vector(0.0, 1.0, 0.0));
+    world_normal.w = 0.0;
+    return v4_normalize(world_normal);
+  }
+  if (sp->type == RT_SHAPE_CUBE) { /* normal_at_cube, lines 756-775: world point, not normalised, w == 1 */
+    double maxc = max3(fabs(point.x), fabs(point.y), fabs(point.z));
+    if (fabs(maxc - fabs(point.x)) < RTO_EPSILON) return v4_point(point.x, 0, 0);
+    if (fabs(maxc - fabs(point.y)) < RTO_EPSILON) return v4_point(0, point.y, 0);
+    return v4_point(0, 0, point.z);
+  }
+  return v4_vector(point.x, 0, point.z); /* normal_at_cylinder, line 777 */
+}
 static v4 normal_at(const world_t* w, long id, v4 point) {
   prim_ref p = w->order[id];
   if (p.kind == 0) return normal_at_sphere(w->s->sph_inv + 16 * (size_t)p.idx, point);
+  if (p.kind == 2) return normal_at_shape(&w->s->shapes[p.idx], point);
   /* normalize(cross(e2, e1)), line 752; create_triangle stores the same value (line 1006) */
   return v4_normalize(v4_cross(tri_row(w->s, p.idx, 6, 0.0), tri_row(w->s, p.idx, 3, 0.0)));
 }
 static const rt_material* material_of(const world_t* w, long id) {
   prim_ref p = w->order[id];
-  int m = p.kind == 0 ? w->s->sph_material[p.idx] : w->s->tri_material[p.idx];
+  int m = p.kind == 0 ? w->s->sph_material[p.idx] : (p.kind == 2 ? w->s->shapes[p.idx].material : w->s->tri_material[p.idx]);
   return &w->s->materials[m];
 }
+static const rt_material_ext* material_ext_of(const world_t* w, const rt_material* m) {
+  return w->s->materials_ext ? &w->s->materials_ext[m - w->s->materials] : NULL;
+}
 
-/* ---- comps / prepare_computations, lines 94, 1360-1376 ---- */
+/* ---- comps / prepare_computations, lines 94, 1360-1408 ---- */
 typedef struct {
-  double t; long id; v4 point, eyev, normalv, over_point, reflectv; int inside;
+  double t; long id; v4 point, eyev, normalv, over_point, under_point, reflectv; int inside; double n1, n2;
 } comps_t;
 
-static comps_t prepare(const world_t* w, const isect_t* hit, const ray_t* r) {
+/* containers, lines 98-102, 180-253: entries are world-list positions, -1 = NULL */
+typedef struct { long e[RTO_LIST_SIZE]; } containers_t;
+static void cont_clear(containers_t* c) { for (int i = 0; i < RTO_LIST_SIZE; ++i) c->e[i] = -1; }
+static int cont_is_empty(const containers_t* c) { return c->e[0] == -1; }
+static long cont_last(const containers_t* c) { /* line 201 */
+  long last = -1;
+  for (int i = 0; i < RTO_LIST_SIZE && c->e[i] != -1; ++i) last = c->e[i];
+  return last;
+}
+static int cont_includes(const containers_t* c, long id) { /* line 213 */
+  for (int i = 0; i < RTO_LIST_SIZE; ++i) if (c->e[i] == id) return 1;
+  return 0;
+}
+static void cont_append(containers_t* c, long id) { /* line 222 */
+  for (int i = 0; i < RTO_LIST_SIZE; ++i) if (c->e[i] == -1) { c->e[i] = id; break; }
+}
+static void cont_remove(containers_t* c, long id) { /* line 233 */
+  int i = 0, found = 0;
+  while (i < RTO_LIST_SIZE && c->e[i] != -1) {
+    if (c->e[i] == id) { found = 1; break; }
+    i++;
+  }
+  if (found) {
+    while (i < RTO_LIST_SIZE - 1 && c->e[i] != -1) {
+      c->e[i] = c->e[i + 1];
+      c->e[i + 1] = -1;
+      i++;
+    }
+  }
+}
+static double refractive_index_of(const world_t* w, long id) {
+  const rt_material_ext* x = material_ext_of(w, material_of(w, id));
+  return x ? x->refractive_index : 1.0; /* create_material_default, line 713 */
+}
+
+static comps_t prepare(const world_t* w, const isect_t* hit, const ray_t* r, const isect_list* xs) {
   comps_t c;
   c.t = hit->t;
   c.id = hit->id;
@@ -231,13 +378,61 @@ static comps_t prepare(const world_t* w, const isect_t* hit, const ray_t* r) {
   if (v4_dot(c.normalv, c.eyev) < 0.0f) { c.inside = 1; c.normalv = v4_neg(c.normalv); }
   else c.inside = 0;
   c.over_point = v4_add(c.point, v4_scale(c.normalv, RTO_EPSILON));
+  c.under_point = v4_sub(c.point, v4_scale(c.normalv, RTO_EPSILON));
   c.reflectv = v4_reflect(r->direction, c.normalv);
+  c.n1 = c.n2 = 1.0; /* the reference leaves them unset when the loop below never reaches the hit */
+  if (xs) { /* refraction section, lines 1378-1406 */
+    containers_t cont;
+    cont_clear(&cont);
+    for (int k = 0; k < xs->count; k++) {
+      const isect_t* i = &xs->e[k];
+      if (i->t == hit->t) c.n1 = cont_is_empty(&cont) ? 1.0f : refractive_index_of(w, cont_last(&cont));
+      if (cont_includes(&cont, i->id)) cont_remove(&cont, i->id);
+      else cont_append(&cont, i->id);
+      if (i->t == hit->t) {
+        c.n2 = cont_is_empty(&cont) ? 1.0f : refractive_index_of(w, cont_last(&cont));
+        break;
+      }
+    }
+  }
   return c;
 }
 
-/* ---- lighting, lines 1273-1320 (has_pattern == false) ---- */
-static v4 lighting(const rt_material* m, const rt_light* light, v4 point, v4 eyev, v4 normalv, int in_shadow) {
+/* ---- pattern_at / stripe_at_object, lines 1166-1206, 1259-1271 ---- */
+static v4 pattern_at(const rt_material_ext* x, v4 point) {
+  v4 from = v4_point(x->pattern_from[0], x->pattern_from[1], x->pattern_from[2]);
+  v4 to = v4_point(x->pattern_to[0], x->pattern_to[1], x->pattern_to[2]);
+  switch (x->pattern_type) {
+    case RT_PATTERN_TEST:
+      return v4_point(point.x, point.y, point.z);
+    case RT_PATTERN_STRIPE:
+      return ((int)floor(point.x) % 2 == 0) ? v4_point(from.x, from.y, from.z) : v4_point(to.x, to.y, to.z);
+    case RT_PATTERN_GRADIENT: {
+      v4 distance = v4_sub(to, from);
+      double fraction = point.x - floor(point.x);
+      return v4_add(from, v4_scale(distance, fraction));
+    }
+    case RT_PATTERN_RING:
+      return ((int)floor(sqrt(point.x * point.x + point.z * point.z)) % 2 == 0) ? from : to;
+    case RT_PATTERN_CHECKER: {
+      int position = (int)(floor(abs((int)point.x)) + floor(abs((int)point.y)) + floor(abs((int)point.z)));
+      return (position % 2 == 0) ? from : to;
+    }
+    default:
+      return v4_point(0.0, 0.0, 0.0);
+  }
+}
+
+/* ---- lighting, lines 1273-1320.  `first_inv`: inverse transform of the world's first object, which is what
+ * shade_hit passes as `sh` (line 1489) ---- */
+static v4 lighting(const rt_material* m, const rt_material_ext* x, const double* first_inv, const rt_light* light,
+                   v4 point, v4 eyev, v4 normalv, int in_shadow) {
   v4 color = v4_make(m->color[0], m->color[1], m->color[2], 1.0);
+  if (x && x->pattern_type != RT_PATTERN_NONE) { /* stripe_at_object, line 1259 */
+    v4 object_point = mat_mul_v4(first_inv, point);
+    v4 pattern_point = mat_mul_v4(x->pattern_inv, object_point);
+    color = pattern_at(x, pattern_point);
+  }
   v4 intensity = v4_make(light->intensity[0], light->intensity[1], light->intensity[2], 1.0);
   v4 light_pos = v4_point(light->position[0], light->position[1], light->position[2]);
   v4 effective_color = v4_mul(color, intensity);
@@ -280,10 +475,26 @@ static int is_shadowed(world_t* w, v4 point) {
 /* ---- color_at / shade_hit / reflected_color, lines 1426-1451, 1485-1499 ---- */
 static v4 color_at(world_t* w, const ray_t* r, int remaining);
 
+static double schlick(const comps_t* c) { /* lines 1470-1483 */
+  double cosine = v4_dot(c->eyev, c->normalv);
+  if (c->n1 > c->n2) {
+    double n = c->n1 / c->n2;
+    double sin2_t = (n * n) * (1.0 - cosine * cosine);
+    if (sin2_t > 1.0) return 1.0;
+    double cos_t = sqrt(1.0 - sin2_t);
+    cosine = cos_t;
+  }
+  double q = (c->n1 - c->n2) / (c->n1 + c->n2);
+  double r0 = q * q;
+  return r0 + (1.0 - r0) * pow((1.0 - cosine), 5);
+}
+
 static v4 shade_hit(world_t* w, const comps_t* c, int remaining) {
   const rt_material* m = material_of(w, c->id);
+  const rt_material_ext* x = material_ext_of(w, m);
+  const double transparency = x ? x->transparency : 0.0;
   int shadowed = is_shadowed(w, c->over_point);
-  v4 surface = lighting(m, &w->s->light, c->over_point, c->eyev, c->normalv, shadowed);
+  v4 surface = lighting(m, x, w->s->first_object_inv, &w->s->light, c->over_point, c->eyev, c->normalv, shadowed);
   v4 reflected;
   if (remaining < 1 || fabs(m->reflective - 0.0) < RTO_EPSILON) { /* equal(), line 262 */
     reflected = v4_point(0.0, 0.0, 0.0);
@@ -294,7 +505,29 @@ static v4 shade_hit(world_t* w, const comps_t* c, int remaining) {
     ++w->rays_secondary;
     reflected = v4_scale(color_at(w, &rr, remaining - 1), m->reflective);
   }
-  v4 refracted = v4_point(0.0, 0.0, 0.0); /* transparency == 0, line 1457 */
+  v4 refracted; /* refracted_color, lines 1453-1468 */
+  {
+    double n_ratio = c->n1 / c->n2;
+    double cos_i = v4_dot(c->eyev, c->normalv);
+    double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+    if (remaining <= 0 || fabs(transparency - 0.0) < RTO_EPSILON || sin2_t > 1.0) {
+      refracted = v4_point(0.0, 0.0, 0.0);
+    } else {
+      double cos_t = sqrt(1.0 - sin2_t);
+      double n_ratio_cos = n_ratio * cos_i - cos_t;
+      v4 eyev_n_ratio = v4_scale(c->eyev, n_ratio);
+      v4 direction = v4_sub(v4_scale(c->normalv, n_ratio_cos), eyev_n_ratio);
+      ray_t fr;
+      fr.origin = v4_point(c->under_point.x, c->under_point.y, c->under_point.z);
+      fr.direction = v4_vector(direction.x, direction.y, direction.z);
+      ++w->rays_secondary;
+      refracted = v4_scale(color_at(w, &fr, remaining - 1), transparency);
+    }
+  }
+  if (m->reflective > 0.0 && transparency > 0.0) { /* lines 1494-1497 */
+    double reflectance = schlick(c);
+    return v4_add(surface, v4_add(v4_scale(reflected, reflectance), v4_scale(refracted, (1.0 - reflectance))));
+  }
   return v4_add(v4_add(surface, reflected), refracted);
 }
 
@@ -304,7 +537,7 @@ static v4 color_at(world_t* w, const ray_t* r, int remaining) {
   isect_world(w, r, &l);
   const isect_t* h = list_hit(&l);
   if (h == NULL) return v4_point(0.0, 0.0, 0.0);
-  comps_t c = prepare(w, h, r);
+  comps_t c = prepare(w, h, r, &l);
   return shade_hit(w, &c, remaining);
 }
 
@@ -443,7 +676,7 @@ void rto_reflect(const double in[3], const double n[3], double out[3]) {
 
 void rto_lighting(const rt_material* m, const rt_light* light, const double point[3], const double eyev[3],
                   const double normalv[3], int in_shadow, double rgb_out[3]) {
-  v4 c = lighting(m, light, v4_point(point[0], point[1], point[2]), v4_vector(eyev[0], eyev[1], eyev[2]),
+  v4 c = lighting(m, NULL, NULL, light, v4_point(point[0], point[1], point[2]), v4_vector(eyev[0], eyev[1], eyev[2]),
                   v4_vector(normalv[0], normalv[1], normalv[2]), in_shadow);
   rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z;
 }
@@ -489,7 +722,7 @@ int rto_prepare(const rt_scene* scene, const rto_ray* r, int order, double t, do
   if (order < 0 || order >= w.n) { world_close(&w); return -2; }
   ray_t q = ray_in(r);
   isect_t h = {t, order};
-  comps_t c = prepare(&w, &h, &q);
+  comps_t c = prepare(&w, &h, &q, NULL);
   const v4* src[5] = {&c.point, &c.eyev, &c.normalv, &c.over_point, &c.reflectv};
   for (int k = 0; k < 5; ++k) { out[3 * k] = src[k]->x; out[3 * k + 1] = src[k]->y; out[3 * k + 2] = src[k]->z; }
   out[15] = c.inside;

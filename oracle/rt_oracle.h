@@ -33,7 +33,7 @@ typedef struct rto_ray {
 /* counters of the last rto_render_* call (probes, not part of the algorithm) */
 typedef struct rto_probe {
   uint64_t max_list;     /* largest intersections.count of any ray            */
-  uint64_t exact_zero_t; /* appended t == 0.0 exactly (RayTracer.c:168 quirk) */
+  uint64_t exact_zero_t; /* list entries with t == 0.0 exactly when the list is sorted (RayTracer.c:168 quirk) */
   uint64_t list_overflow;/* appends refused because the list held 100 entries */
 } rto_probe;
 

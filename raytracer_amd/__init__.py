@@ -6,7 +6,7 @@ Python plumbing used by tests, bench.py and the multi-GPU gather.
 """
 from . import _ffi
 from .render import HipRenderer, RtError, make_params, ppm_bytes, rank_row_map
-from .scene import Mat4, SceneBuilder, default_material, lighthouse_triangles, scene_arrays, stock_scene
+from .scene import Mat4, SceneBuilder, default_material, lighthouse_triangles, material_ext, scene_arrays, stock_scene
 
 __all__ = [
     "_ffi", "HipRenderer", "RtError", "make_params", "ppm_bytes", "rank_row_map",

@@ -33,6 +33,34 @@ class Material(C.Structure):
     ]
 
 
+RT_PATTERN_NONE, RT_PATTERN_TEST, RT_PATTERN_STRIPE, RT_PATTERN_GRADIENT, RT_PATTERN_RING, RT_PATTERN_CHECKER = -1, 0, 1, 2, 3, 4
+RT_SHAPE_PLANE, RT_SHAPE_CUBE, RT_SHAPE_CYLINDER = 0, 3, 4
+
+
+class MaterialExt(C.Structure):
+    _fields_ = [
+        ("transparency", C.c_double),
+        ("refractive_index", C.c_double),
+        ("pattern_from", C.c_double * 3),
+        ("pattern_to", C.c_double * 3),
+        ("pattern_inv", C.c_double * 16),
+        ("pattern_type", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Shape(C.Structure):
+    _fields_ = [
+        ("inv", C.c_double * 16),
+        ("minimum", C.c_double),
+        ("maximum", C.c_double),
+        ("type", C.c_int32),
+        ("closed", C.c_int32),
+        ("material", C.c_int32),
+        ("order", C.c_int32),
+    ]
+
+
 class Camera(C.Structure):
     _fields_ = [
         ("hsize", C.c_int32),
@@ -74,6 +102,10 @@ class Scene(C.Structure):
         ("n_bvh_nodes", C.c_int32),
         ("bvh_nodes", C.POINTER(BvhNode)),
         ("bvh_tri", C.POINTER(C.c_int32)),
+        ("n_shapes", C.c_int32),
+        ("shapes", C.POINTER(Shape)),
+        ("materials_ext", C.POINTER(MaterialExt)),
+        ("first_object_inv", C.c_double * 16),
     ]
 
 
@@ -128,6 +160,10 @@ def host_lib():
         L.rt_scene_set_camera_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp]
         L.rt_scene_set_light.argtypes = [C.c_void_p, _dp, _dp]
         L.rt_scene_add_sphere.argtypes = [C.c_void_p, _dp, C.POINTER(Material)]
+        L.rt_scene_add_sphere_ext.argtypes = [C.c_void_p, _dp, C.POINTER(Material), C.POINTER(MaterialExt), _dp]
+        L.rt_scene_add_shape.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(Material), C.POINTER(MaterialExt), _dp,
+                                         C.c_double, C.c_double, C.c_int]
+        L.rt_material_ext_default.restype = MaterialExt
         L.rt_scene_add_triangle.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(Material)]
         L.rt_scene_add_triangles_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(Material)]
         L.rt_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(Material)]

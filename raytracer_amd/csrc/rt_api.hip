@@ -400,6 +400,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       (sc->n_tris && (!sc->tri_soa || !sc->tri_material || !sc->tri_order)))
     return RT_ERR_INVALID;
   if ((long long)sc->camera.hsize * sc->camera.vsize > (1ll << 31) / 3) return RT_ERR_TOO_LARGE;
+  if (sc->n_shapes != 0 || sc->materials_ext) return RT_ERR_UNSUPPORTED;
   const int ns = sc->n_spheres, nt = sc->n_tris;
   const int n_prims = ns + nt;
 

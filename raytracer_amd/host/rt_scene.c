@@ -144,6 +144,9 @@ rt_material rt_material_default(void) {
 /* -------------------------------------------------------------- builder -- */
 typedef struct { double transform[16]; int material; int order; } sphere_rec;
 typedef struct { double p1[3], p2[3], p3[3]; int material; int order; } tri_rec;
+typedef struct { double transform[16]; double minimum, maximum; int type, closed, material, order; } shape_rec;
+/* the pattern half of a material as the caller gives it (transform, not its inverse) */
+typedef struct { rt_material_ext x; double pattern_transform[16]; } ext_rec;
 
 struct rt_scene_builder {
   rt_camera camera;
@@ -151,8 +154,14 @@ struct rt_scene_builder {
   rt_light light;
   sphere_rec* spheres; int n_spheres, cap_spheres;
   tri_rec* tris; int n_tris, cap_tris;
+  shape_rec* shapes; int n_shapes, cap_shapes;
   rt_material* materials; int n_materials, cap_materials;
+  ext_rec* exts; int cap_exts;      /* parallel to materials */
+  int any_ext;                      /* some material has a pattern or transparency / refractive index */
+  int n_objects;                    /* length of the world list so far */
+  double first_transform[16];       /* transform of the world's first object */
   /* outputs of rt_scene_finish */
+  rt_shape* out_shapes; rt_material_ext* out_exts;
   double* sph_inv; int32_t* sph_material; int32_t* sph_order;
   double* tri_soa; int32_t* tri_material; int32_t* tri_order;
   rt_bvh_node* bvh_nodes; int32_t* bvh_tri; int n_bvh_nodes;
@@ -164,6 +173,8 @@ static void free_outputs(rt_scene_builder* b) {
   free(b->sph_inv); free(b->sph_material); free(b->sph_order);
   free(b->tri_soa); free(b->tri_material); free(b->tri_order);
   free(b->bvh_nodes); free(b->bvh_tri);
+  free(b->out_shapes); free(b->out_exts);
+  b->out_shapes = NULL; b->out_exts = NULL;
   b->sph_inv = b->tri_soa = NULL;
   b->sph_material = b->sph_order = b->tri_material = b->tri_order = b->bvh_tri = NULL;
   b->bvh_nodes = NULL;
@@ -173,7 +184,7 @@ static void free_outputs(rt_scene_builder* b) {
 void rt_scene_destroy(rt_scene_builder* b) {
   if (!b) return;
   free_outputs(b);
-  free(b->spheres); free(b->tris); free(b->materials);
+  free(b->spheres); free(b->tris); free(b->shapes); free(b->materials); free(b->exts);
   free(b);
 }
 
@@ -187,14 +198,47 @@ static int grow(void** p, int* cap, int need, size_t elem) {
   return 1;
 }
 
-static int intern_material(rt_scene_builder* b, const rt_material* m) {
+rt_material_ext rt_material_ext_default(void) { /* create_material_default, RayTracer.c:712-717 */
+  rt_material_ext x;
+  memset(&x, 0, sizeof x);
+  x.transparency = 0.0;
+  x.refractive_index = 1.0;
+  x.pattern_to[0] = x.pattern_to[1] = x.pattern_to[2] = 1.0;
+  rt_mat4_identity(x.pattern_inv);
+  x.pattern_type = RT_PATTERN_NONE;
+  return x;
+}
+
+/* `x` NULL = default (opaque, no pattern); pattern_transform NULL = identity (the pattern constructors, :1209-1257) */
+static int intern_material_ext(rt_scene_builder* b, const rt_material* m, const rt_material_ext* x,
+                               const double* pattern_transform) {
   rt_material d = rt_material_default();
   if (!m) m = &d;
+  ext_rec e;
+  memset(&e, 0, sizeof e);
+  e.x = x ? *x : rt_material_ext_default();
+  e.x.reserved = 0;
+  if (pattern_transform) memcpy(e.pattern_transform, pattern_transform, sizeof e.pattern_transform);
+  else rt_mat4_identity(e.pattern_transform);
+  rt_mat4_identity(e.x.pattern_inv); /* derived in rt_scene_finish */
   for (int i = b->n_materials - 1; i >= 0 && i >= b->n_materials - 8; --i)
-    if (memcmp(&b->materials[i], m, sizeof *m) == 0) return i;
+    if (memcmp(&b->materials[i], m, sizeof *m) == 0 && memcmp(&b->exts[i], &e, sizeof e) == 0) return i;
   if (!grow((void**)&b->materials, &b->cap_materials, b->n_materials + 1, sizeof *m)) return -1;
+  if (!grow((void**)&b->exts, &b->cap_exts, b->n_materials + 1, sizeof e)) return -1;
   b->materials[b->n_materials] = *m;
+  b->exts[b->n_materials] = e;
+  if (x) b->any_ext = 1;
   return b->n_materials++;
+}
+static int intern_material(rt_scene_builder* b, const rt_material* m) { return intern_material_ext(b, m, NULL, NULL); }
+
+/* position in the world list of the object being appended (add_shape_to_world, RayTracer.c:1078) */
+static int next_order(rt_scene_builder* b, const double* transform) {
+  if (b->n_objects == 0) {
+    if (transform) memcpy(b->first_transform, transform, sizeof b->first_transform);
+    else rt_mat4_identity(b->first_transform); /* a triangle keeps create_shape's identity, :976 */
+  }
+  return b->n_objects++;
 }
 
 int rt_scene_set_camera_view(rt_scene_builder* b, int hsize, int vsize, double fov, const double view[16]) {
@@ -232,15 +276,39 @@ int rt_scene_set_light(rt_scene_builder* b, const double position[3], const doub
   return RT_OK;
 }
 
-int rt_scene_add_sphere(rt_scene_builder* b, const double transform[16], const rt_material* m) {
+int rt_scene_add_sphere_ext(rt_scene_builder* b, const double transform[16], const rt_material* m,
+                            const rt_material_ext* x, const double* pattern_transform) {
   if (!b || !transform) return RT_ERR_INVALID;
   if (!grow((void**)&b->spheres, &b->cap_spheres, b->n_spheres + 1, sizeof(sphere_rec))) return RT_ERR_INVALID;
-  int mi = intern_material(b, m);
+  int mi = intern_material_ext(b, m, x, pattern_transform);
   if (mi < 0) return RT_ERR_INVALID;
   sphere_rec* s = &b->spheres[b->n_spheres++];
   memcpy(s->transform, transform, sizeof s->transform);
   s->material = mi;
-  s->order = b->n_spheres - 1 + b->n_tris;
+  s->order = next_order(b, transform);
+  return s->order;
+}
+
+int rt_scene_add_sphere(rt_scene_builder* b, const double transform[16], const rt_material* m) {
+  return rt_scene_add_sphere_ext(b, transform, m, NULL, NULL);
+}
+
+int rt_scene_add_shape(rt_scene_builder* b, int type, const double transform[16], const rt_material* m,
+                       const rt_material_ext* x, const double* pattern_transform, double minimum, double maximum,
+                       int closed) {
+  if (!b || !transform) return RT_ERR_INVALID;
+  if (type != RT_SHAPE_PLANE && type != RT_SHAPE_CUBE && type != RT_SHAPE_CYLINDER) return RT_ERR_INVALID;
+  if (!grow((void**)&b->shapes, &b->cap_shapes, b->n_shapes + 1, sizeof(shape_rec))) return RT_ERR_INVALID;
+  int mi = intern_material_ext(b, m, x, pattern_transform);
+  if (mi < 0) return RT_ERR_INVALID;
+  shape_rec* s = &b->shapes[b->n_shapes++];
+  memcpy(s->transform, transform, sizeof s->transform);
+  s->type = type;
+  s->minimum = minimum;
+  s->maximum = maximum;
+  s->closed = closed != 0;
+  s->material = mi;
+  s->order = next_order(b, transform);
   return s->order;
 }
 
@@ -255,7 +323,7 @@ int rt_scene_add_triangle(rt_scene_builder* b, const double p1[3], const double 
   memcpy(t->p2, p2, sizeof t->p2);
   memcpy(t->p3, p3, sizeof t->p3);
   t->material = mi;
-  t->order = b->n_spheres + b->n_tris - 1;
+  t->order = next_order(b, NULL);
   return t->order;
 }
 
@@ -275,15 +343,17 @@ int rt_scene_set_reflective(rt_scene_builder* b, double tri_reflective, double s
   /* materials are shared by index: give every primitive class its own copies */
   for (int i = 0; i < b->n_tris; ++i) {
     rt_material m = b->materials[b->tris[i].material];
+    const ext_rec e = b->exts[b->tris[i].material];
     m.reflective = tri_reflective;
-    int mi = intern_material(b, &m);
+    int mi = intern_material_ext(b, &m, &e.x, e.pattern_transform);
     if (mi < 0) return RT_ERR_INVALID;
     b->tris[i].material = mi;
   }
   for (int i = 0; i < b->n_spheres; ++i) {
     rt_material m = b->materials[b->spheres[i].material];
+    const ext_rec e = b->exts[b->spheres[i].material];
     m.reflective = sph_reflective;
-    int mi = intern_material(b, &m);
+    int mi = intern_material_ext(b, &m, &e.x, e.pattern_transform);
     if (mi < 0) return RT_ERR_INVALID;
     b->spheres[i].material = mi;
   }
@@ -369,6 +439,7 @@ int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out) {
   if (!b || !out) return RT_ERR_INVALID;
   if (!b->have_camera || !b->have_light) return RT_ERR_NOT_READY;
   free_outputs(b);
+  memset(out, 0, sizeof *out);
   const int ns = b->n_spheres, nt = b->n_tris;
   b->sph_inv = malloc(sizeof(double) * 16 * (size_t)(ns ? ns : 1));
   b->sph_material = malloc(sizeof(int32_t) * (size_t)(ns ? ns : 1));
@@ -403,7 +474,6 @@ int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out) {
     b->tri_order[i] = t->order;
   }
 
-  memset(out, 0, sizeof *out);
   out->camera = b->camera;
   out->light = b->light;
   out->n_materials = b->n_materials;
@@ -416,6 +486,38 @@ int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out) {
   out->tri_soa = b->tri_soa;
   out->tri_material = b->tri_material;
   out->tri_order = b->tri_order;
+
+  /* planes, cubes, cylinders; patterns and transparency */
+  if (b->n_shapes > 0) {
+    b->out_shapes = malloc(sizeof(rt_shape) * (size_t)b->n_shapes);
+    if (!b->out_shapes) return RT_ERR_INVALID;
+    for (int i = 0; i < b->n_shapes; ++i) {
+      const shape_rec* r = &b->shapes[i];
+      rt_shape* o = &b->out_shapes[i];
+      memset(o, 0, sizeof *o);
+      rt_mat4_identity(o->inv); /* mat4x4_set_ident before mat4x4_inverse, RayTracer.c:899-900 */
+      if (!rt_mat4_inverse(r->transform, o->inv)) return RT_ERR_UNSUPPORTED;
+      o->minimum = r->minimum;
+      o->maximum = r->maximum;
+      o->type = r->type;
+      o->closed = r->closed;
+      o->material = r->material;
+      o->order = r->order;
+    }
+    out->n_shapes = b->n_shapes;
+    out->shapes = b->out_shapes;
+  }
+  if (b->any_ext && b->n_materials > 0) {
+    b->out_exts = malloc(sizeof(rt_material_ext) * (size_t)b->n_materials);
+    if (!b->out_exts) return RT_ERR_INVALID;
+    for (int i = 0; i < b->n_materials; ++i) {
+      b->out_exts[i] = b->exts[i].x;
+      if (!rt_mat4_inverse(b->exts[i].pattern_transform, b->out_exts[i].pattern_inv)) return RT_ERR_UNSUPPORTED;
+    }
+    out->materials_ext = b->out_exts;
+  }
+  rt_mat4_identity(out->first_object_inv);
+  if (b->n_objects > 0 && !rt_mat4_inverse(b->first_transform, out->first_object_inv)) return RT_ERR_UNSUPPORTED;
 
   if (bvh_leaf_size > 0 && nt > 0) {
     double* p123 = malloc(sizeof(double) * 9 * (size_t)nt);
@@ -519,10 +621,216 @@ static int add_complete_world_spheres(rt_scene_builder* b) { /* RayTracer.c:5852
   return RT_OK;
 }
 
+static rt_material_ext checkers(double from, double to) { /* checkers_pattern, RayTracer.c:1249 */
+  rt_material_ext x = rt_material_ext_default();
+  x.pattern_type = RT_PATTERN_CHECKER;
+  x.pattern_from[0] = x.pattern_from[1] = x.pattern_from[2] = from;
+  x.pattern_to[0] = x.pattern_to[1] = x.pattern_to[2] = to;
+  return x;
+}
+
+/* T * S the way the scene functions build it: identity * translate, then * scale (e.g. RayTracer.c:6332-6335) */
+static void ident_translate_scale(double tx, double ty, double tz, double sx, double sy, double sz, double m[16]) {
+  double t[16], sc[16];
+  rt_mat4_translate(tx, ty, tz, t);
+  rt_mat4_scale(sx, sy, sz, sc);
+  rt_mat4_identity(m);
+  rt_mat4_mul(m, t, m);
+  rt_mat4_mul(m, sc, m);
+}
+
+static int add_world_with_plane(rt_scene_builder* b) { /* render_complete_world_with_plane, RayTracer.c:6227-6396 */
+  double m[16], t[16], rot[16], pt[16];
+  int rc;
+  const double ninf = -INFINITY, pinf = INFINITY;
+  rt_material fm = rt_material_default(); /* floor_material, reused for the walls with its colour changed */
+  fm.color[0] = fm.color[1] = fm.color[2] = 1.0;
+  fm.specular = 0.0;
+  fm.reflective = 0.0;
+  rt_material_ext fx = checkers(0.15, 0.85);
+  rt_mat4_identity(m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, m, &fm, &fx, NULL, ninf, pinf, 0)) < 0) return rc; /* floor */
+  rt_mat4_rotate_z(M_PI / 2.0, rot);
+  fm.color[0] = 0.0; fm.color[1] = 0.0; fm.color[2] = 1.0;
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, rot, &fm, &fx, NULL, ninf, pinf, 0)) < 0) return rc; /* right wall */
+  fm.color[0] = 1.0; fm.color[1] = 0.0; fm.color[2] = 0.0;
+  rt_mat4_rotate_x(-M_PI / 2.0, rot);
+  rt_mat4_translate(0.0, 0.0, -2.75, t);
+  rt_mat4_mul(rot, t, rot);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, rot, &fm, &fx, NULL, ninf, pinf, 0)) < 0) return rc; /* left wall */
+
+  /* glass sphere: create_glass_sphere (:1017) then :6274-6277 */
+  rt_material gm = rt_material_default();
+  rt_material_ext gx = rt_material_ext_default();
+  gm.diffuse = 0.0;
+  gx.refractive_index = 1.5;
+  gx.transparency = 0.9;
+  gm.reflective = 0.2;
+  rt_mat4_translate(-7.0, 1.0, -8.0, m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &gm, &gx, NULL)) < 0) return rc;
+
+  /* middle sphere: purple stripes scaled by 0.175 */
+  rt_material mm = rt_material_default();
+  mm.color[0] = 0.1; mm.color[1] = 1.0; mm.color[2] = 0.5;
+  mm.diffuse = 0.7; mm.specular = 0.3;
+  rt_material_ext mx = rt_material_ext_default();
+  mx.pattern_type = RT_PATTERN_STRIPE;
+  mx.pattern_from[0] = mx.pattern_from[1] = mx.pattern_from[2] = 1.0;
+  mx.pattern_to[0] = 0.439; mx.pattern_to[1] = 0.305; mx.pattern_to[2] = 0.827;
+  rt_mat4_scale(0.175, 0.175, 0.175, pt);
+  rt_mat4_translate(-3.5, 1.0, -3.0, m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &mm, &mx, pt)) < 0) return rc;
+
+  /* right sphere: black mirror */
+  rt_material rm = rt_material_default();
+  rm.color[0] = rm.color[1] = rm.color[2] = 0.0;
+  rm.diffuse = 0.7; rm.specular = 0.3; rm.reflective = 1.0;
+  ident_translate_scale(-1.95, 1.0, -5.5, 0.5, 0.5, 0.5, m);
+  if ((rc = rt_scene_add_sphere(b, m, &rm)) < 0) return rc;
+
+  /* small sphere: dark stripes scaled by 0.07; 0.8f is a float literal (:6365) */
+  rt_material sm = rt_material_default();
+  sm.color[0] = 1.0; sm.color[1] = 0.8f; sm.color[2] = 0.1;
+  sm.diffuse = 0.7; sm.specular = 0.3; sm.shininess = 100.0;
+  rt_material_ext sx = rt_material_ext_default();
+  sx.pattern_type = RT_PATTERN_STRIPE;
+  sx.pattern_from[0] = sx.pattern_from[1] = sx.pattern_from[2] = 0.2;
+  sx.pattern_to[0] = sx.pattern_to[1] = sx.pattern_to[2] = 0.0;
+  rt_mat4_scale(0.07, 0.07, 0.07, pt);
+  ident_translate_scale(-6.5, 0.33, -2.75, 0.33, 0.33, 0.33, m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &sm, &sx, pt)) < 0) return rc;
+
+  /* origin sphere: default material, green */
+  rt_material om = rt_material_default();
+  om.color[0] = 0.0; om.color[2] = 0.0;
+  rt_mat4_identity(m);
+  if ((rc = rt_scene_add_sphere(b, m, &om)) < 0) return rc;
+  return RT_OK;
+}
+
+static int add_dual_spheres(rt_scene_builder* b) { /* render_dual_spheres_refracting_on_floor, RayTracer.c:6432-6485 */
+  double m[16], rot[16], pos[16];
+  int rc;
+  rt_material sm = rt_material_default();
+  sm.ambient = 0.0;
+  sm.color[0] = sm.color[1] = sm.color[2] = 1.0;
+  sm.diffuse = 0.0; sm.specular = 0.9; sm.shininess = 300.0; sm.reflective = 0.9;
+  rt_material_ext sx = rt_material_ext_default();
+  sx.transparency = 0.9;
+  sx.refractive_index = 1.0000034;
+  rt_mat4_scale(0.5, 0.5, 0.5, m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &sm, &sx, NULL)) < 0) return rc; /* hollow centre */
+  sx.refractive_index = 1.5;
+  rt_mat4_identity(m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &sm, &sx, NULL)) < 0) return rc; /* outer sphere */
+  rt_material wm = rt_material_default();
+  wm.ambient = 0.8f; wm.diffuse = 0.2; wm.specular = 0.0;
+  rt_material_ext wx = checkers(0.15, 0.85);
+  rt_mat4_rotate_x(M_PI / 2.0, rot);
+  rt_mat4_translate(0.0, 0.0, 10.0, pos);
+  rt_mat4_mul(pos, rot, pos);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, pos, &wm, &wx, NULL, -INFINITY, INFINITY, 0)) < 0) return rc;
+  return RT_OK;
+}
+
+static int add_refraction_scene(rt_scene_builder* b) { /* render_refraction_scene, RayTracer.c:6504-6710 */
+  double m[16], t[16], r1[16], r2[16];
+  int rc;
+  const double ninf = -INFINITY, pinf = INFINITY;
+  rt_material fm = rt_material_default();
+  fm.ambient = 0.5; fm.diffuse = 0.4; fm.specular = 0.8; fm.reflective = 0.2;
+  rt_material_ext cx = checkers(0.0, 0.75);
+  rt_mat4_translate(0.0, 0.1, 0.0, t);
+  rt_mat4_identity(m);
+  rt_mat4_mul(m, t, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, m, &fm, &cx, NULL, ninf, pinf, 0)) < 0) return rc; /* floor */
+
+  rt_material wm = rt_material_default();
+  wm.specular = 0;
+  rt_mat4_translate(5.0, 0.0, 0.0, t);
+  rt_mat4_rotate_y(1.5708, r1);
+  rt_mat4_rotate_z(1.5708, r2);
+  rt_mat4_identity(m);
+  rt_mat4_mul(r1, m, m);
+  rt_mat4_mul(r2, m, m);
+  rt_mat4_mul(t, m, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, m, &wm, &cx, NULL, ninf, pinf, 0)) < 0) return rc; /* right wall */
+  rt_mat4_translate(0.0, 0.0, 5.0, t);
+  rt_mat4_rotate_x(1.5708, r1);
+  rt_mat4_identity(m);
+  rt_mat4_mul(r1, m, m);
+  rt_mat4_mul(t, m, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, m, &wm, &cx, NULL, ninf, pinf, 0)) < 0) return rc; /* left wall */
+  rt_mat4_translate(0.0, 0.0, -5.0, t);
+  rt_mat4_identity(m);
+  rt_mat4_mul(r1, m, m);
+  rt_mat4_mul(t, m, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_PLANE, m, &wm, &cx, NULL, ninf, pinf, 0)) < 0) return rc; /* wall behind */
+
+  rt_material bm = rt_material_default();
+  bm.color[0] = 0.8; bm.color[1] = 0.1; bm.color[2] = 0.3;
+  rt_mat4_translate(4, 1, 4, m);
+  if ((rc = rt_scene_add_sphere(b, m, &bm)) < 0) return rc; /* red ball */
+  bm = rt_material_default();
+  bm.color[0] = 0.2; bm.color[1] = 0.1; bm.color[2] = 0.8;
+  bm.shininess = 10; bm.specular = 0.9;
+  rt_mat4_translate(2.3, 0.6, 4.4, t);
+  rt_mat4_scale(0.6, 0.6, 0.6, r1);
+  rt_mat4_mul(t, r1, t);
+  if ((rc = rt_scene_add_sphere(b, t, &bm)) < 0) return rc; /* blue ball */
+  bm = rt_material_default();
+  bm.color[0] = 0.1; bm.color[1] = 0.8; bm.color[2] = 0.2;
+  bm.shininess = 200;
+  rt_mat4_translate(4.6, 0.4, 2.9, t);
+  rt_mat4_scale(0.4, 0.4, 0.4, r1);
+  rt_mat4_mul(t, r1, t);
+  if ((rc = rt_scene_add_sphere(b, t, &bm)) < 0) return rc; /* green ball */
+
+  rt_material mm = rt_material_default(); /* mirror ball; refractive_index 0.0 as the scene sets it (:6648) */
+  mm.color[0] = mm.color[1] = mm.color[2] = 0.0;
+  mm.ambient = 0; mm.diffuse = 0.0; mm.specular = 0.9; mm.shininess = 300; mm.reflective = 1.0;
+  rt_material_ext mx = rt_material_ext_default();
+  mx.transparency = 0.0;
+  mx.refractive_index = 0.0;
+  ident_translate_scale(2.2, 0.6, 0.0, 0.5, 0.5, 0.5, m);
+  if ((rc = rt_scene_add_sphere_ext(b, m, &mm, &mx, NULL)) < 0) return rc;
+
+  ident_translate_scale(-0.60, 0.25, 0.80, 0.125, 0.125, 0.125, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_CUBE, m, NULL, NULL, NULL, ninf, pinf, 0)) < 0) return rc;
+
+  rt_material cm = rt_material_default();
+  cm.color[0] = 1.000; cm.color[1] = 0.766; cm.color[2] = 0.336;
+  cm.shininess = 300; cm.reflective = 1.0; cm.ambient = 0.25;
+  ident_translate_scale(.65, .21, -0.75, 0.175, 0.25, 0.175, m);
+  if ((rc = rt_scene_add_shape(b, RT_SHAPE_CYLINDER, m, &cm, NULL, NULL, 0.0, 0.20, 0)) < 0) return rc;
+  return RT_OK;
+}
+
 int rt_scene_stock(rt_scene_builder* b, const char* name, int hsize, int vsize) {
   if (!b || !name) return RT_ERR_INVALID;
   const double up[3] = {0.0, 1.0, 0.0};
   int rc;
+  if (!strcmp(name, "world_with_plane")) {
+    const double from[3] = {-10.0, 1.5, -10.0}, to[3] = {0.0, 0.0, 0.0};
+    const double lp[3] = {-10.0, 10.0, -10.0}, li[3] = {1.0, 1.0, 1.0};
+    if ((rc = add_world_with_plane(b)) != RT_OK) return rc;
+    if ((rc = rt_scene_set_light(b, lp, li)) != RT_OK) return rc;
+    return rt_scene_set_camera(b, hsize, vsize, M_PI / 3.0, from, to, up);
+  }
+  if (!strcmp(name, "dual_spheres")) {
+    const double from[3] = {0.0, 0.0, -5.0}, to[3] = {0.0, 0.0, 0.0};
+    const double lp[3] = {2.0, 10.0, -5.0}, li[3] = {0.9, 0.9, 0.9};
+    if ((rc = rt_scene_set_camera(b, hsize, vsize, 0.45, from, to, up)) != RT_OK) return rc;
+    if ((rc = rt_scene_set_light(b, lp, li)) != RT_OK) return rc;
+    return add_dual_spheres(b);
+  }
+  if (!strcmp(name, "refraction")) {
+    const double from[3] = {-4.5, 1.75, -4.7}, to[3] = {0.0, 0.85, 0.0};
+    const double lp[3] = {-3.0, 3.0, 1}, li[3] = {1, 1, 1};
+    if ((rc = rt_scene_set_camera(b, hsize, vsize, 0.5, from, to, up)) != RT_OK) return rc;
+    if ((rc = rt_scene_set_light(b, lp, li)) != RT_OK) return rc;
+    return add_refraction_scene(b);
+  }
   if (!strcmp(name, "cube") || !strcmp(name, "lighthouse")) {
     const int lh = !strcmp(name, "lighthouse");
     const double from_c[3] = {10.0, 10.0, -5.0}, to_c[3] = {0.0, 0.0, 0.0};

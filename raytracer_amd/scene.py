@@ -133,6 +133,24 @@ class SceneBuilder:
         m = C.byref(material) if material is not None else None
         return check(self._L.rt_scene_add_sphere(self._b, _m16(t), m), "add_sphere")
 
+    def add_sphere_ext(self, transform=None, material=None, ext=None, pattern_transform=None):
+        """A sphere whose material has a pattern and/or transparency (ext: _ffi.MaterialExt)."""
+        t = Mat4.identity() if transform is None else transform
+        m = C.byref(material) if material is not None else None
+        x = C.byref(ext) if ext is not None else None
+        pt = _m16(pattern_transform) if pattern_transform is not None else None
+        return check(self._L.rt_scene_add_sphere_ext(self._b, _m16(t), m, x, pt), "add_sphere_ext")
+
+    def add_shape(self, kind, transform=None, material=None, ext=None, pattern_transform=None,
+                  minimum=-math.inf, maximum=math.inf, closed=False):
+        """kind: 'plane' | 'cube' | 'cylinder' (create_shape, RayTracer.c:968)."""
+        ty = {"plane": _ffi.RT_SHAPE_PLANE, "cube": _ffi.RT_SHAPE_CUBE, "cylinder": _ffi.RT_SHAPE_CYLINDER}[kind]
+        t = Mat4.identity() if transform is None else transform
+        m = C.byref(material) if material is not None else None
+        x = C.byref(ext) if ext is not None else None
+        pt = _m16(pattern_transform) if pattern_transform is not None else None
+        return check(self._L.rt_scene_add_shape(self._b, ty, _m16(t), m, x, pt, minimum, maximum, int(closed)), "add_shape")
+
     def add_triangle(self, p1, p2, p3, material=None):
         m = C.byref(material) if material is not None else None
         return check(self._L.rt_scene_add_triangle(self._b, _d3(p1), _d3(p2), _d3(p3), m), "add_triangle")
@@ -184,8 +202,20 @@ def lighthouse_triangles():
     return np.fromfile(path, dtype="<f4").reshape(-1, 9)
 
 
+def material_ext(**kw):
+    """Pattern / transparency half of a material, defaults of create_material_default (RayTracer.c:712-717)."""
+    x = _ffi.host_lib().rt_material_ext_default()
+    for k, v in kw.items():
+        if k in ("pattern_from", "pattern_to"):
+            getattr(x, k)[:] = list(v)
+        else:
+            setattr(x, k, v)
+    return x
+
+
 def stock_scene(name, hsize, vsize, tri_reflective=0.0, sph_reflective=0.0, bvh_leaf_size=4):
-    """The reference's scenes at any size: 'lighthouse', 'cube' (the teapot.h mesh), 'spheres', 'cube_spheres'."""
+    """The reference's scenes at any size: 'lighthouse', 'cube' (the teapot.h mesh), 'spheres', 'cube_spheres',
+    'refraction', 'world_with_plane', 'dual_spheres'."""
     b = SceneBuilder()
     b.stock(name, hsize, vsize)
     if name == "lighthouse":
@@ -206,6 +236,9 @@ def scene_arrays(s):
         "tri_soa": np.ctypeslib.as_array(s.tri_soa, shape=(12, max(nt, 1)))[:, :nt].copy() if nt else np.zeros((12, 0)),
         "tri_order": np.ctypeslib.as_array(s.tri_order, shape=(max(nt, 1),))[:nt].copy(),
         "tri_material": np.ctypeslib.as_array(s.tri_material, shape=(max(nt, 1),))[:nt].copy(),
+        "first_object_inv": np.array(s.first_object_inv[:]).reshape(4, 4),
+        "shapes": [s.shapes[i] for i in range(s.n_shapes)],
+        "materials_ext": [s.materials_ext[i] for i in range(s.n_materials)] if s.materials_ext else None,
     }
     return out
 
@@ -215,6 +248,7 @@ __all__ = [
     "Mat4",
     "default_material",
     "stock_scene",
+    "material_ext",
     "scene_arrays",
     "lighthouse_triangles",
     "Material",

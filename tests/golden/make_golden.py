@@ -24,6 +24,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refdump  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "rt_ref_harness")
+# the reference's OWN scene functions feeding the harness loop (render() interposed): planes, patterns, glass, ...
+CAPTURE = os.path.join(ROOT, "oracle", "_ref", "rt_ref_capture")
 OBJ = "/root/reference/RayTracer/lighthouse.obj"
 
 # name -> harness arguments.  f64 canvases are kept for the small cases only.
@@ -46,8 +48,20 @@ CASES = {
     "cube_101x37": dict(scene="cube", size=(101, 37), f64=True),
     "spheres_33x71": dict(scene="spheres", size=(33, 71), f64=True),
     "lighthouse_refl_320x180": dict(scene="lighthouse", size=(320, 180), tri_refl=0.3, rgb=True, f64=False),
+    # the scenes beyond spheres and triangles, built by the reference's own scene functions
+    "refraction_300": dict(scene="refraction", size=(300, 300), rgb=True, f64=False, capture=True),
+    "world_with_plane_300": dict(scene="world_with_plane", size=(300, 300), rgb=True, f64=False, capture=True),
+    "dual_spheres_300": dict(scene="dual_spheres", size=(300, 300), rgb=True, f64=False, capture=True),
+    "refraction_96x64": dict(scene="refraction", size=(96, 64), f64=True, dump=True, capture=True),
+    "world_with_plane_96x64": dict(scene="world_with_plane", size=(96, 64), f64=True, dump=True, capture=True),
+    "dual_spheres_96x64": dict(scene="dual_spheres", size=(96, 64), f64=True, dump=True, capture=True),
+    "refraction_ss2_48x32": dict(scene="refraction", size=(48, 32), spp=2, f64=True, capture=True),
+    "world_with_plane_77x45": dict(scene="world_with_plane", size=(77, 45), f64=True, capture=True),
 }
 BIG = {
+    "refraction_1080p": dict(scene="refraction", size=(1920, 1080), rgb=True, f64=False, capture=True),
+    "world_with_plane_1080p": dict(scene="world_with_plane", size=(1920, 1080), rgb=True, f64=False, capture=True),
+    "dual_spheres_1080p": dict(scene="dual_spheres", size=(1920, 1080), rgb=True, f64=False, capture=True),
     "lighthouse_1080p": dict(scene="lighthouse", size=(1920, 1080), rgb=True, f64=False),
     "cube_1080p": dict(scene="cube", size=(1920, 1080), rgb=True, f64=False),
     "spheres_1080p": dict(scene="spheres", size=(1920, 1080), rgb=True, f64=False),
@@ -57,6 +71,8 @@ BIG = {
 def run_case(name, c, tmp):
     w, h = c["size"]
     args = [HARNESS, "--scene", c["scene"], "--size", str(w), str(h), "--obj", OBJ]
+    if c.get("capture"):
+        args = [CAPTURE, "--capture", "--scene", c["scene"], "--size", str(w), str(h)]
     if c.get("spp", 1) != 1:
         args += ["--spp-grid", str(c["spp"])]
     if c.get("tri_refl"):
@@ -91,8 +107,8 @@ def run_case(name, c, tmp):
         np.savez_compressed(os.path.join(HERE, name + ".rgb.npz"), rgb=rgb)
         entry["rgb"] = name + ".rgb.npz"
     if c.get("dump"):
-        head, shapes = refdump.load(dump)
-        refdump.save_npz(os.path.join(HERE, name + ".scene.npz"), head, shapes)
+        head, shapes, ext = refdump.load(dump)
+        refdump.save_npz(os.path.join(HERE, name + ".scene.npz"), head, shapes, ext)
         entry["scene_dump"] = name + ".scene.npz"
     return entry
 
@@ -100,7 +116,7 @@ def run_case(name, c, tmp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
-    ap.add_argument("--only", default=None)
+    ap.add_argument("--only", default=None, help="one case name, or a prefix ending in *")
     a = ap.parse_args()
     if not os.path.exists(HARNESS):
         sys.exit("build the reference first: make -C oracle ref")
@@ -111,7 +127,7 @@ def main():
         cases.update(BIG)
     with tempfile.TemporaryDirectory() as tmp:
         for name, c in cases.items():
-            if a.only and a.only != name:
+            if a.only and not (a.only == name or (a.only.endswith("*") and name.startswith(a.only[:-1]))):
                 continue
             manifest[name] = run_case(name, c, tmp)
             print(name, manifest[name]["rays"], manifest[name]["ppm_sha256"][:16], flush=True)
@@ -119,7 +135,7 @@ def main():
         dump = os.path.join(tmp, "lh.scene")
         subprocess.run([HARNESS, "--scene", "lighthouse", "--size", "8", "8", "--obj", OBJ, "--no-render",
                         "--dump-scene", dump], check=True, capture_output=True)
-        head, shapes = refdump.load(dump)
+        head, shapes, _ = refdump.load(dump)
         tri = shapes[shapes["type"] == refdump.TRIANGLE]
         xyz9 = np.concatenate([tri["p1"][:, :3], tri["p2"][:, :3], tri["p3"][:, :3]], axis=1)
         f32 = xyz9.astype("<f4")

@@ -45,7 +45,22 @@ HEAD_DTYPE = np.dtype(
         ("pad", "<i4"),
     ]
 )
-SPHERE, TRIANGLE = 1, 2  # enum shape_type, RayTracer.c:69
+# second section of a dump: cylinder bounds, pattern
+EXT_DTYPE = np.dtype(
+    [
+        ("minimum", "<f8"),
+        ("maximum", "<f8"),
+        ("closed", "<i4"),
+        ("has_pattern", "<i4"),
+        ("pattern_type", "<i4"),
+        ("pad", "<i4"),
+        ("pattern_from", "<f8", 4),
+        ("pattern_to", "<f8", 4),
+        ("pattern_transform", "<f8", (4, 4)),
+        ("pattern_inverse", "<f8", (4, 4)),
+    ]
+)
+PLANE, SPHERE, TRIANGLE, CUBE, CYLINDER = 0, 1, 2, 3, 4  # enum shape_type, RayTracer.c:69
 
 
 def parse(raw):
@@ -53,19 +68,30 @@ def parse(raw):
     assert head["magic"] == b"RTSCENE1", head["magic"]
     n = int(head["n_shapes"])
     shapes = np.frombuffer(raw, dtype=SHAPE_DTYPE, count=n, offset=HEAD_DTYPE.itemsize)
-    assert HEAD_DTYPE.itemsize + n * SHAPE_DTYPE.itemsize == len(raw)
-    return head, shapes
+    end = HEAD_DTYPE.itemsize + n * SHAPE_DTYPE.itemsize
+    if end == len(raw):
+        return head, shapes
+    assert raw[end:end + 8] == b"RTEXT001" and end + 8 + n * EXT_DTYPE.itemsize == len(raw)
+    return head, shapes, np.frombuffer(raw, dtype=EXT_DTYPE, count=n, offset=end + 8)
 
 
 def load(path):
+    """(head, shapes, ext); ext is None for dumps without the second section."""
     with open(path, "rb") as f:
-        return parse(f.read())
+        r = parse(f.read())
+    return r if len(r) == 3 else (r[0], r[1], None)
 
 
-def save_npz(path, head, shapes):
-    np.savez_compressed(path, head=np.array([head], dtype=HEAD_DTYPE), shapes=np.asarray(shapes, dtype=SHAPE_DTYPE))
+def save_npz(path, head, shapes, ext=None):
+    extra = {} if ext is None else {"ext": np.asarray(ext, dtype=EXT_DTYPE)}
+    np.savez_compressed(path, head=np.array([head], dtype=HEAD_DTYPE), shapes=np.asarray(shapes, dtype=SHAPE_DTYPE), **extra)
 
 
 def load_npz(path):
     z = np.load(path, allow_pickle=False)
     return z["head"][0], z["shapes"]
+
+
+def load_npz_ext(path):
+    z = np.load(path, allow_pickle=False)
+    return z["head"][0], z["shapes"], (z["ext"] if "ext" in z.files else None)
