@@ -184,13 +184,15 @@ static int isect_triangle_t(v4 p1, v4 e1, v4 e2, const ray_t* r, double* t_out) 
 
 /* ---- plane / cube / cylinder branches of intersect_all_but_triangle, lines 898-918 ---- */
 static double max3(double a, double b, double c) { /* line 687 */
-  double m = a;
+  double m = -INFINITY;
+  if (a > m) m = a;
   if (b > m) m = b;
   if (c > m) m = c;
   return m;
 }
 static double min3(double a, double b, double c) { /* line 695 */
-  double m = a;
+  double m = INFINITY;
+  if (a < m) m = a;
   if (b < m) m = b;
   if (c < m) m = c;
   return m;

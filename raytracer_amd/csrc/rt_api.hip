@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_kernels.hip.inc"
+#include "rt_general.hip.inc"
 #include "rt_ppm.hip.inc"
 
 namespace {
@@ -58,6 +59,13 @@ struct Context {
   size_t d_rgb_bytes = 0;
   double* d_canvas = nullptr;
   size_t d_canvas_bytes = 0;
+  /* worlds with planes, cubes, cylinders, patterns or transparency: the general kernel's copy of the scene */
+  bool general = false;
+  int gen_list_cap = 100;
+  int gen_hsize = 0, gen_vsize = 0;
+  GenScene* d_gen_scene = nullptr;
+  GenObject* d_gen_objects = nullptr;
+  GenMaterial* d_gen_materials = nullptr;
   /* P3 formatter: per-chunk lengths and offsets, library-owned text buffer, pinned word for the length */
   unsigned* d_ppm_len = nullptr;
   unsigned long long* d_ppm_off = nullptr;
@@ -82,7 +90,18 @@ bool hip_ok(hipError_t e, const char* what) {
     if (!hip_ok((call), #call)) return RT_ERR_HIP; \
   } while (0)
 
+void free_general() {
+  if (g.d_gen_scene) (void)hipFree(g.d_gen_scene);
+  if (g.d_gen_objects) (void)hipFree(g.d_gen_objects);
+  if (g.d_gen_materials) (void)hipFree(g.d_gen_materials);
+  g.d_gen_scene = nullptr;
+  g.d_gen_objects = nullptr;
+  g.d_gen_materials = nullptr;
+  g.general = false;
+}
+
 void free_scene() {
+  free_general();
   if (g.d_spheres) (void)hipFree(g.d_spheres);
   if (g.d_tris) (void)hipFree(g.d_tris);
   if (g.d_normals) (void)hipFree(g.d_normals);
@@ -283,6 +302,129 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
   return RT_OK;
 }
 
+/* A world that needs the general kernel: one object array in world-list order, full 4x4 inverses, materials
+ * with their pattern and transparency halves. */
+int upload_general(const rt_scene* sc) {
+  const int ns = sc->n_spheres, nt = sc->n_tris, nsh = sc->n_shapes;
+  const long long n_ll = (long long)ns + nt + nsh;
+  if (nsh < 0 || (nsh > 0 && !sc->shapes)) return RT_ERR_INVALID;
+  if (n_ll > (1 << 20)) return RT_ERR_TOO_LARGE; /* every ray visits every object: this path is for small worlds */
+  const int n = (int)n_ll;
+  if (n > 0 && (sc->n_materials < 1 || !sc->materials)) return RT_ERR_INVALID;
+  std::vector<GenObject> objs((size_t)(n > 0 ? n : 1));
+  std::vector<char> seen((size_t)(n > 0 ? n : 1), 0);
+  long long max_entries = 0; /* the most intersections one ray can append */
+  auto place = [&](int order, int material) -> GenObject* {
+    if (order < 0 || order >= n || seen[order]) return nullptr;
+    if (material < 0 || material >= sc->n_materials) return nullptr;
+    seen[order] = 1;
+    GenObject* o = &objs[order];
+    memset(o, 0, sizeof *o);
+    o->material = material;
+    return o;
+  };
+  for (int i = 0; i < ns; ++i) {
+    GenObject* o = place(sc->sph_order[i], sc->sph_material[i]);
+    if (!o) return RT_ERR_INVALID;
+    o->kind = GEN_SPHERE;
+    memcpy(o->m, sc->sph_inv + 16 * (size_t)i, sizeof o->m);
+    max_entries += 2;
+  }
+  for (int i = 0; i < nt; ++i) {
+    GenObject* o = place(sc->tri_order[i], sc->tri_material[i]);
+    if (!o) return RT_ERR_INVALID;
+    o->kind = GEN_TRIANGLE;
+    for (int r = 0; r < 12; ++r) o->m[r] = sc->tri_soa[(size_t)r * nt + i];
+    max_entries += 1;
+  }
+  for (int i = 0; i < nsh; ++i) {
+    const rt_shape& sh = sc->shapes[i];
+    GenObject* o = place(sh.order, sh.material);
+    if (!o) return RT_ERR_INVALID;
+    if (sh.type == RT_SHAPE_PLANE) { o->kind = GEN_PLANE; max_entries += 1; }
+    else if (sh.type == RT_SHAPE_CUBE) { o->kind = GEN_CUBE; max_entries += 2; }
+    else if (sh.type == RT_SHAPE_CYLINDER) { o->kind = GEN_CYLINDER; max_entries += 4; }
+    else return RT_ERR_UNSUPPORTED;
+    memcpy(o->m, sh.inv, sizeof o->m);
+    o->minimum = sh.minimum;
+    o->maximum = sh.maximum;
+    o->closed = sh.closed != 0;
+  }
+  std::vector<GenMaterial> mats((size_t)(sc->n_materials > 0 ? sc->n_materials : 1));
+  for (int i = 0; i < sc->n_materials; ++i) {
+    GenMaterial& m = mats[i];
+    memset(&m, 0, sizeof m);
+    const rt_material& a = sc->materials[i];
+    memcpy(m.color, a.color, sizeof m.color);
+    m.ambient = a.ambient; m.diffuse = a.diffuse; m.specular = a.specular; m.shininess = a.shininess;
+    m.reflective = a.reflective;
+    m.transparency = 0.0;
+    m.refractive_index = 1.0; /* create_material_default, RayTracer.c:713 */
+    m.pattern_type = RT_PATTERN_NONE;
+    if (sc->materials_ext) {
+      const rt_material_ext& x = sc->materials_ext[i];
+      if (x.pattern_type < RT_PATTERN_NONE || x.pattern_type > RT_PATTERN_CHECKER) return RT_ERR_INVALID;
+      m.transparency = x.transparency;
+      m.refractive_index = x.refractive_index;
+      memcpy(m.pattern_from, x.pattern_from, sizeof m.pattern_from);
+      memcpy(m.pattern_to, x.pattern_to, sizeof m.pattern_to);
+      memcpy(m.pattern_inv, x.pattern_inv, sizeof m.pattern_inv);
+      m.pattern_type = x.pattern_type;
+    }
+  }
+  GenScene hd;
+  memset(&hd, 0, sizeof hd);
+  hd.pixel_size = sc->camera.pixel_size;
+  hd.half_width = sc->camera.half_width;
+  hd.half_height = sc->camera.half_height;
+  memcpy(hd.inv_view, sc->camera.inv_view, sizeof hd.inv_view);
+  memcpy(hd.light_pos, sc->light.position, sizeof hd.light_pos);
+  memcpy(hd.light_int, sc->light.intensity, sizeof hd.light_int);
+  memcpy(hd.first_inv, sc->first_object_inv, sizeof hd.first_inv);
+  hd.hsize = sc->camera.hsize;
+  hd.vsize = sc->camera.vsize;
+  hd.n_objects = n;
+
+  free_scene();
+  HIP_TRY(hipMalloc((void**)&g.d_gen_scene, sizeof hd));
+  HIP_TRY(hipMemcpy(g.d_gen_scene, &hd, sizeof hd, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&g.d_gen_objects, sizeof(GenObject) * objs.size()));
+  HIP_TRY(hipMemcpy(g.d_gen_objects, objs.data(), sizeof(GenObject) * objs.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&g.d_gen_materials, sizeof(GenMaterial) * mats.size()));
+  HIP_TRY(hipMemcpy(g.d_gen_materials, mats.data(), sizeof(GenMaterial) * mats.size(), hipMemcpyHostToDevice));
+  /* a short list when no ray can fill it; otherwise the reference's 100 slots, overflow behaviour included */
+  g.gen_list_cap = max_entries <= 32 ? 32 : 100;
+  g.general = true;
+  g.scene = DevScene{};
+  g.scene.hsize = sc->camera.hsize;
+  g.scene.vsize = sc->camera.vsize;
+  g.host_camera = sc->camera;
+  g.reflective = false;
+  g.have_scene = true;
+  ++g.scene_serial;
+  return RT_OK;
+}
+
+template <bool COUNT, bool F64OUT>
+void launch_general_cap(dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  const dim3 block(RT_TILE_W * RT_TILE_H);
+  if (g.gen_list_cap <= 32)
+    hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 32>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
+                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, rgb, canvas, g.d_counters);
+  else
+    hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 100>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
+                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, rgb, canvas, g.d_counters);
+}
+void launch_general(bool count, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  if (count) {
+    if (f64) launch_general_cap<true, true>(grid, s, a, rgb, canvas);
+    else launch_general_cap<true, false>(grid, s, a, rgb, canvas);
+  } else {
+    if (f64) launch_general_cap<false, true>(grid, s, a, rgb, canvas);
+    else launch_general_cap<false, false>(grid, s, a, rgb, canvas);
+  }
+}
+
 int check_params(const rt_render_params* p) {
   if (!p) return RT_ERR_INVALID;
   if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
@@ -320,13 +462,21 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
     if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     int n_blocks = 0;
-    const int prc = plan_tiles(p, rows, s, a, n_blocks);
-    if (prc != RT_OK) return prc;
+    if (g.general) {
+      a.n_heavy = (int)n_tiles;
+      a.light_per_block = 1;
+      n_blocks = (int)n_tiles;
+      bvh = false;
+    } else {
+      const int prc = plan_tiles(p, rows, s, a, n_blocks);
+      if (prc != RT_OK) return prc;
+    }
     a.pad = 0;
     (void)n_tiles;
     dim3 grid((unsigned)n_blocks);
     if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
-    launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
+    if (g.general) launch_general(count, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
+    else launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
     if (stats) HIP_TRY(hipEventRecord(g.ev1, s));
   }
@@ -400,7 +550,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       (sc->n_tris && (!sc->tri_soa || !sc->tri_material || !sc->tri_order)))
     return RT_ERR_INVALID;
   if ((long long)sc->camera.hsize * sc->camera.vsize > (1ll << 31) / 3) return RT_ERR_TOO_LARGE;
-  if (sc->n_shapes != 0 || sc->materials_ext) return RT_ERR_UNSUPPORTED;
+  if (sc->n_shapes != 0 || sc->materials_ext) return upload_general(sc);
   const int ns = sc->n_spheres, nt = sc->n_tris;
   const int n_prims = ns + nt;
 

@@ -27,8 +27,20 @@ static rt_material rt_binding_material(const material* m) {
   return o;
 }
 
-/* returns RT_OK or a negative rt_status; RT_ERR_UNSUPPORTED means the world holds something outside the
- * accelerated path (plane, cube, cylinder, pattern, transparency) and the caller should keep its CPU loop */
+/* transparency, refractive index and pattern of a `material` (RayTracer.c:57); NULL-equivalent when all default */
+static rt_material_ext rt_binding_material_ext(const material* m) {
+  rt_material_ext x = rt_material_ext_default();
+  x.transparency = m->transparency;
+  x.refractive_index = m->refractive_index;
+  if (m->has_pattern) {
+    x.pattern_type = (int)m->pattern.type; /* RT_PATTERN_* carry the values of enum pattern_type */
+    x.pattern_from[0] = m->pattern.from.x; x.pattern_from[1] = m->pattern.from.y; x.pattern_from[2] = m->pattern.from.z;
+    x.pattern_to[0] = m->pattern.to.x; x.pattern_to[1] = m->pattern.to.y; x.pattern_to[2] = m->pattern.to.z;
+  }
+  return x;
+}
+
+/* returns RT_OK or a negative rt_status; on an error the caller keeps its CPU loop */
 int rt_render_hip(camera* c, world* w) {
   if ((int)c->hsize != HORIZONTAL_SIZE || (int)c->vsize != VERTICAL_SIZE) return RT_ERR_UNSUPPORTED; /* canvas[][] is fixed */
   rt_scene_builder* b = rt_scene_create();
@@ -38,14 +50,22 @@ int rt_render_hip(camera* c, world* w) {
   const double li[3] = {w->lights->intensity.x, w->lights->intensity.y, w->lights->intensity.z};
   if (rc == RT_OK) rc = rt_scene_set_light(b, lp, li);
   for (shape* sp = w->objects; sp && rc >= 0; sp = sp->next) {
-    if (sp->material.has_pattern || sp->material.transparency != 0.0) { rc = RT_ERR_UNSUPPORTED; break; }
     rt_material m = rt_binding_material(&sp->material);
+    rt_material_ext x = rt_binding_material_ext(&sp->material);
+    const int plain = !sp->material.has_pattern && sp->material.transparency == 0.0 && sp->material.refractive_index == 1.0;
+    const rt_material_ext* xp = plain ? NULL : &x;
+    const double* pt = sp->material.has_pattern ? &sp->material.pattern.transform[0][0] : NULL;
     if (sp->type == SPHERE) {
-      rc = rt_scene_add_sphere(b, &sp->transform[0][0], &m);
+      rc = rt_scene_add_sphere_ext(b, &sp->transform[0][0], &m, xp, pt);
     } else if (sp->type == TRIANGLE) {
       const double p1[3] = {sp->p1.x, sp->p1.y, sp->p1.z}, p2[3] = {sp->p2.x, sp->p2.y, sp->p2.z},
                    p3[3] = {sp->p3.x, sp->p3.y, sp->p3.z};
-      rc = rt_scene_add_triangle(b, p1, p2, p3, &m);
+      rc = plain ? rt_scene_add_triangle(b, p1, p2, p3, &m) : RT_ERR_UNSUPPORTED;
+    } else if (sp->type == PLANE || sp->type == CUBE) {
+      rc = rt_scene_add_shape(b, sp->type == PLANE ? RT_SHAPE_PLANE : RT_SHAPE_CUBE, &sp->transform[0][0], &m, xp, pt,
+                              -INFINITY, INFINITY, 0);
+    } else if (sp->type == CYLINDER) {
+      rc = rt_scene_add_shape(b, RT_SHAPE_CYLINDER, &sp->transform[0][0], &m, xp, pt, sp->minimum, sp->maximum, sp->closed);
     } else {
       rc = RT_ERR_UNSUPPORTED;
     }

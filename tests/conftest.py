@@ -30,7 +30,9 @@ def load_golden(entry, key):
 
 def quantise(canvas):
     """color_convert (RayTracer.c:1322) on a double canvas."""
-    return np.clip(np.trunc(canvas * 255.0), 0, 255).astype(np.uint8)
+    v = canvas * 255.0
+    ok = (v > -2147483649.0) & (v < 2147483648.0)  # anything else casts to INT_MIN on x86-64, i.e. 0 after the clamp
+    return np.clip(np.trunc(np.where(ok, v, 0.0)), 0, 255).astype(np.uint8)
 
 
 @pytest.fixture(scope="session")

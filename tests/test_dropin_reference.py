@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref not built (reference sources absent at build time)")
-@pytest.mark.parametrize("scene,golden", [("cube", "cube_300"), ("spheres", "spheres_300")])
+@pytest.mark.parametrize("scene,golden", [("cube", "cube_300"), ("spheres", "spheres_300"),
+                                          ("refraction", "refraction_300"), ("world_with_plane", "world_with_plane_300"),
+                                          ("dual_spheres", "dual_spheres_300")])
 def test_reference_scene_functions_render_through_the_library(tmp_path, manifest, scene, golden):
     out = subprocess.run([EXE, scene], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
@@ -25,6 +27,9 @@ def test_reference_scene_functions_render_through_the_library(tmp_path, manifest
 @pytest.mark.parametrize("scene,golden,extra", [
     ("cube", "cube_300", []),
     ("spheres", "spheres_300", []),
+    ("refraction", "refraction_300", []),
+    ("world_with_plane", "world_with_plane_300", []),
+    ("dual_spheres", "dual_spheres_300", []),
     ("lighthouse", "lighthouse_300", ["--tris-f32", os.path.join(ROOT, "raytracer_amd", "data", "lighthouse_tris_f32.bin")]),
 ])
 def test_c_host_program_writes_the_reference_ppm(tmp_path, manifest, scene, golden, extra):
