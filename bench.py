@@ -93,6 +93,26 @@ def side_measurements(hip, dev, steps=100):
     return out
 
 
+def general_measurements(hip, dev, steps=20):
+    """The reference's other scene functions (planes, patterns, cube, cylinder, glass) through the general kernel."""
+    out = {}
+    buf = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
+    for scene in ("refraction", "world_with_plane", "dual_spheres"):
+        hip.upload(R.stock_scene(scene, WIDTH, HEIGHT))
+        st = R._ffi.Stats()
+        hip.render_device(buf.data_ptr(), R.make_params(count_rays=True), stats=st)
+        p = R.make_params()
+        for _ in range(2):
+            hip.render_device(buf.data_ptr(), p)
+        hip.timer_start()
+        for _ in range(steps):
+            hip.render_device(buf.data_ptr(), p)
+        hip.timer_stop()
+        ms = hip.timer_ms() / steps
+        out[scene + "_1080p"] = {"rays": st.rays, "kernel_ms": round(ms, 4), "mrays_s": round(st.rays / ms / 1e3, 1)}
+    return out
+
+
 def ppm_measurements(hip, dev, steps=50):
     """The step after the path: write_canvas_to_file's P3 text (RayTracer.c:1333) formatted on the device.
     HBM-bound; algorithmic bytes = the image read twice (lengths, then text) + the text written."""
@@ -316,6 +336,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(total_rays)
         if world == 1 and not a.no_side:
             line["other_scenes_1080p"] = side_measurements(hip, dev)
+            line["general_kernel_scenes"] = general_measurements(hip, dev)
             line["ppm_text_on_device_random_image"] = ppm_measurements(hip, dev)
         print(json.dumps(line), flush=True)
     if world > 1:

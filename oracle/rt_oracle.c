@@ -732,6 +732,50 @@ int rto_prepare(const rt_scene* scene, const rto_ray* r, int order, double t, do
   return c.inside;
 }
 
+int rto_intersect_shape(const rt_shape* sp, const rto_ray* r, double* ts, int cap) {
+  isect_list l;
+  list_init(&l);
+  ray_t q = ray_in(r);
+  isect_shape(sp, &q, &l, 0);
+  for (int i = 0; i < l.count && i < cap; ++i) ts[i] = l.e[i].t;
+  return l.count;
+}
+
+void rto_normal_at_shape(const rt_shape* sp, const double point[3], double n_out[4]) {
+  v4 n = normal_at_shape(sp, v4_point(point[0], point[1], point[2]));
+  n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z; n_out[3] = n.w;
+}
+
+void rto_pattern_at(const rt_material_ext* x, const double point[3], double rgb_out[3]) {
+  v4 c = pattern_at(x, v4_point(point[0], point[1], point[2]));
+  rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z;
+}
+
+double rto_schlick(const double eyev[3], const double normalv[3], double n1, double n2) {
+  comps_t c;
+  memset(&c, 0, sizeof c);
+  c.eyev = v4_vector(eyev[0], eyev[1], eyev[2]);
+  c.normalv = v4_vector(normalv[0], normalv[1], normalv[2]);
+  c.n1 = n1;
+  c.n2 = n2;
+  return schlick(&c);
+}
+
+/* n1 and n2 of the hit at sorted position `hit_index` of a ray through the world (prepare_computations, :1378-1406) */
+int rto_refractive_indices(const rt_scene* scene, const rto_ray* r, int hit_index, double n_out[2]) {
+  world_t w;
+  if (world_open(&w, scene) != RT_OK) return -2;
+  isect_list l;
+  list_init(&l);
+  ray_t q = ray_in(r);
+  isect_world(&w, &q, &l);
+  if (hit_index < 0 || hit_index >= l.count) { world_close(&w); return -1; }
+  comps_t c = prepare(&w, &l.e[hit_index], &q, &l);
+  n_out[0] = c.n1; n_out[1] = c.n2;
+  world_close(&w);
+  return l.count;
+}
+
 int rto_hit_list(const double* ts, int n) {
   isect_list l;
   list_init(&l);

@@ -2,10 +2,11 @@
  * rt_oracle.h - TEST INFRASTRUCTURE, not product code.
  *
  * CPU restatement, in plain C, of the reference's per-pixel trace loop
- * (render(), RayTracer/RayTracer.c:1574 and everything below it), taking the
- * same flattened scene the HIP library takes (include/rt_hip.h).  It follows
+ * (render(), RayTracer/RayTracer.c:1574 and everything below it: spheres,
+ * triangles, planes, cubes, cylinders, patterns, reflection, refraction),
+ * taking the same flattened scene the HIP library takes (include/rt_hip.h).  It follows
  * the reference statement by statement - 4-component tuples, the 100-slot
- * intersection list, libc qsort, hit() - so that it can be compared with the
+ * intersection list, libc qsort, hit(), the container list - so that it can be compared with the
  * reference bit for bit on the double-precision canvas, and the HIP kernels
  * are then compared with it.
  *
@@ -59,6 +60,13 @@ int rto_is_shadowed(const rt_scene* scene, const double point[3]);        /* Ray
 void rto_color_at(const rt_scene* scene, const rto_ray* r, int remaining, double rgb_out[3]); /* RayTracer.c:1426 */
 /* prepare_computations: out = point[3], eyev[3], normalv[3], over_point[3], reflectv[3], inside */
 int rto_prepare(const rt_scene* scene, const rto_ray* r, int order, double t, double out[16]); /* RayTracer.c:1360 */
+
+/* plane / cube / cylinder branch of intersect_all_but_triangle (RayTracer.c:904-918): t values in append order */
+int rto_intersect_shape(const rt_shape* sp, const rto_ray* r, double* ts, int cap);
+void rto_normal_at_shape(const rt_shape* sp, const double point[3], double n_out[4]); /* RayTracer.c:721-790 */
+void rto_pattern_at(const rt_material_ext* x, const double point[3], double rgb_out[3]); /* RayTracer.c:1166 */
+double rto_schlick(const double eyev[3], const double normalv[3], double n1, double n2); /* RayTracer.c:1470 */
+int rto_refractive_indices(const rt_scene* scene, const rto_ray* r, int hit_index, double n_out[2]); /* :1378-1406 */
 
 /* intersections list alone: append ts[0..n) in order, sort, hit(); returns the insertion index of the hit or -1
  * (RayTracer.c:159, 139, 143) */

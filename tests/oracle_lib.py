@@ -49,6 +49,14 @@ def lib():
         L.rto_color_at.argtypes = [SP, C.POINTER(Ray), C.c_int, _dp]
         L.rto_color_at.restype = None
         L.rto_prepare.argtypes = [SP, C.POINTER(Ray), C.c_int, C.c_double, _dp]
+        L.rto_intersect_shape.argtypes = [C.POINTER(_ffi.Shape), C.POINTER(Ray), _dp, C.c_int]
+        L.rto_normal_at_shape.argtypes = [C.POINTER(_ffi.Shape), _dp, _dp]
+        L.rto_normal_at_shape.restype = None
+        L.rto_pattern_at.argtypes = [C.POINTER(_ffi.MaterialExt), _dp, _dp]
+        L.rto_pattern_at.restype = None
+        L.rto_schlick.argtypes = [_dp, _dp, C.c_double, C.c_double]
+        L.rto_schlick.restype = C.c_double
+        L.rto_refractive_indices.argtypes = [SP, C.POINTER(Ray), C.c_int, _dp]
         L.rto_hit_list.argtypes = [_dp, C.c_int]
         L.rto_list_capacity.argtypes = [C.c_int]
         L.rto_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]

@@ -277,3 +277,130 @@ def test_mutually_reflective_surfaces_terminate():
     col = (C.c_double * 3)()
     O.lib().rto_color_at(C.byref(b.finish(0)), C.byref(O.ray((0, 0, 0), (0, 1, 0))), 5, col)
     assert np.isfinite(col[:]).all()
+
+
+# ---- planes, cubes, cylinders, patterns, Schlick: the reference's tests at RayTracer.c:4456-4850, 5262-5720 ----
+def shape(kind, transform=None, minimum=-math.inf, maximum=math.inf, closed=False):
+    sh = R._ffi.Shape()
+    sh.inv[:] = list(np.asarray(R.Mat4.inverse(R.Mat4.identity() if transform is None else transform)).reshape(16))
+    sh.minimum, sh.maximum, sh.closed = minimum, maximum, int(closed)
+    sh.type = {"plane": R._ffi.RT_SHAPE_PLANE, "cube": R._ffi.RT_SHAPE_CUBE, "cylinder": R._ffi.RT_SHAPE_CYLINDER}[kind]
+    return sh
+
+
+def shape_ts(sh, origin, direction, normalise=False):
+    d = np.asarray(direction, dtype=float)
+    if normalise:
+        d = d / np.sqrt((d * d).sum())
+    t = (C.c_double * 8)()
+    n = O.lib().rto_intersect_shape(C.byref(sh), C.byref(O.ray(origin, d)), t, 8)
+    return n, list(t[:n])
+
+
+def test_plane_intersections():  # :4483-4529
+    pl = shape("plane")
+    assert shape_ts(pl, (0, 10, 0), (0, 0, 1))[0] == 0
+    assert shape_ts(pl, (0, 0, 0), (0, 0, 1))[0] == 0
+    assert shape_ts(pl, (0, 1, 0), (0, -1, 0)) == (1, [1.0])
+    assert shape_ts(pl, (0, -1, 0), (0, 1, 0)) == (1, [1.0])
+    n = (C.c_double * 4)()
+    for p in ((0, 0, 0), (10, 0, -10), (-5, 0, 150)):  # normal_of_plane_is_const_everywhere_test, :4456
+        O.lib().rto_normal_at_shape(C.byref(pl), O.d3(p), n)
+        assert close(n[:], (0, 1, 0, 0))
+
+
+@pytest.mark.parametrize("origin,direction", [((5, 0.5, 0), (-1, 0, 0)), ((-5, 0.5, 0), (1, 0, 0)), ((0.5, 5, 0), (0, -1, 0)),
+                                              ((0.5, -5, 0), (0, 1, 0)), ((0.5, 0, 5), (0, 0, -1)), ((0.5, 0, -5), (0, 0, 1))])
+def test_ray_intersects_cube(origin, direction):  # ray_intersects_cube_test, :5367
+    n, ts = shape_ts(shape("cube"), origin, direction)
+    assert n == 2 and close(ts, (4, 6))
+
+
+def test_ray_inside_cube_and_misses():  # ray inside the cube (:5367-5422), ray_misses_cube_test (:5424)
+    n, ts = shape_ts(shape("cube"), (0, 0.5, 0), (0, 0, 1))
+    assert n == 2 and close(ts, (-1, 1))
+    for o, d in (((-2, 0, 0), (0.2673, 0.5345, 0.8018)), ((0, -2, 0), (0.8018, 0.2673, 0.5345)), ((0, 0, -2), (0.5345, 0.8018, 0.2673)),
+                 ((2, 0, 2), (0, 0, -1)), ((0, 2, 2), (0, -1, 0)), ((2, 2, 0), (-1, 0, 0))):
+        assert shape_ts(shape("cube"), o, d)[0] == 0
+
+
+def test_normal_on_surface_of_cube():  # :5462: the point itself decides, unnormalised, returned as a point (w == 1)
+    cu = shape("cube")
+    n = (C.c_double * 4)()
+    for p, want in (((1, 0.5, -0.8), (1, 0, 0)), ((-1, -0.2, 0.9), (-1, 0, 0)), ((-0.4, 1, -0.1), (0, 1, 0)),
+                    ((0.3, -1, -0.7), (0, -1, 0)), ((-0.6, 0.3, 1), (0, 0, 1)), ((0.4, 0.4, -1), (0, 0, -1)),
+                    ((1, 1, 1), (1, 0, 0)), ((-1, -1, -1), (-1, 0, 0))):
+        O.lib().rto_normal_at_shape(C.byref(cu), O.d3(p), n)
+        assert close(n[:3], want) and n[3] == 1.0
+
+
+def test_cylinder_intersections():  # :5517-5720
+    cyl = shape("cylinder")
+    for o, d in (((1, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 1, 0)), ((0, 0, -5), (1, 1, 1))):  # ray_misses_cylinder_test
+        assert shape_ts(cyl, o, d, normalise=True)[0] == 0
+    assert close(shape_ts(cyl, (1, 0, -5), (0, 0, 1), True)[1], (5, 5))
+    assert close(shape_ts(cyl, (0, 0, -5), (0, 0, 1), True)[1], (4, 6))
+    assert close(shape_ts(cyl, (0.5, 0, -5), (0.1, 1, 1), True)[1], (6.8079819, 7.0887234))
+    lim = shape("cylinder", minimum=1.0, maximum=2.0)  # intersecting_constrained_cylinder, :5621
+    for o, d, want in (((0, 1.5, 0), (0.1, 1, 0), 0), ((0, 3, -5), (0, 0, 1), 0), ((0, 0, -5), (0, 0, 1), 0),
+                       ((0, 2, -5), (0, 0, 1), 0), ((0, 1, -5), (0, 0, 1), 0), ((0, 1.5, -2), (0, 0, 1), 2)):
+        assert shape_ts(lim, o, d)[0] == want
+    capped = shape("cylinder", minimum=1.0, maximum=2.0, closed=True)  # intersecting_caps_of_closed_cylinder_test, :5671
+    for o, d in (((0, 3, 0), (0, -1, 0)), ((0, 3, -2), (0, -1, 2)), ((0, 4, -2), (0, -1, 1)), ((0, 0, -2), (0, 1, 2)),
+                 ((0, -1, -2), (0, 1, 1))):
+        assert shape_ts(capped, o, d, normalise=True)[0] == 2
+    n = (C.c_double * 4)()
+    for p, want in (((1, 0, 0), (1, 0, 0)), ((0, 5, -1), (0, 0, -1)), ((0, -2, 1), (0, 0, 1)), ((-1, 1, 0), (-1, 0, 0))):
+        O.lib().rto_normal_at_shape(C.byref(cyl), O.d3(p), n)  # normal_vector_on_cylinder_test, :5590
+        assert close(n[:], (*want, 0))
+
+
+def pattern_colour(kind, point, frm=(1, 1, 1), to=(0, 0, 0)):
+    x = R.material_ext(pattern_type=kind, pattern_from=frm, pattern_to=to)
+    out = (C.c_double * 3)()
+    O.lib().rto_pattern_at(C.byref(x), O.d3(point), out)
+    return list(out)
+
+
+def test_patterns():  # :4531-4850
+    P = R._ffi
+    W, B = [1, 1, 1], [0, 0, 0]
+    for p, want in (((0, 0, 0), W), ((0, 1, 0), W), ((0, 2, 0), W), ((0, 0, 1), W), ((0, 0, 2), W), ((0.9, 0, 0), W),
+                    ((1, 0, 0), B), ((-0.1, 0, 0), B), ((-1, 0, 0), B), ((-1.1, 0, 0), W)):
+        assert pattern_colour(P.RT_PATTERN_STRIPE, p) == want, p
+    for p, want in (((0, 0, 0), W), ((1, 0, 0), B), ((0, 0, 1), B), ((float(np.float32(0.708)), 0, float(np.float32(0.708))), B)):
+        assert pattern_colour(P.RT_PATTERN_RING, p) == want, p
+    for p, want in (((0, 0, 0), W), ((0.99, 0, 0), W), ((1.01, 0, 0), B), ((0, 0.99, 0), W), ((0, 1.01, 0), B),
+                    ((0, 0, 0.99), W), ((0, 0, 1.01), B)):
+        assert pattern_colour(P.RT_PATTERN_CHECKER, p) == want, p
+    assert close(pattern_colour(P.RT_PATTERN_GRADIENT, (0.25, 0, 0)), (0.75, 0.75, 0.75))  # gradiant_linearly_interpolates_between_colors_test, :4722
+    assert close(pattern_colour(P.RT_PATTERN_GRADIENT, (0.5, 0, 0)), (0.5, 0.5, 0.5))
+    assert close(pattern_colour(P.RT_PATTERN_GRADIENT, (0.75, 0, 0)), (0.25, 0.25, 0.25))
+    assert pattern_colour(P.RT_PATTERN_TEST, (2, 3, 4)) == [2, 3, 4]
+
+
+def test_schlick():  # :5262-5298: eyev / normalv as prepare_computations leaves them for those rays
+    L = O.lib()
+    assert close(L.rto_schlick(O.d3((0, -1, 0)), O.d3((0, -1, 0)), 1.5, 1.0), 0.04)  # perpendicular, from inside
+    assert close(L.rto_schlick(O.d3((0, -1, 0)), O.d3((-S2, 0, -S2)), 1.5, 1.0), 1.0)  # total internal reflection
+    # small angle, n2 > n1: ray (0, 0.99, -2) -> +z hits the unit glass sphere at t = 1.8589
+    pz = -2 + 1.8589
+    nrm = np.array([0, 0.99, pz]) / np.sqrt(0.99 ** 2 + pz ** 2)
+    assert close(L.rto_schlick(O.d3((0, 0, -1)), O.d3(nrm), 1.0, 1.5), 0.48873)
+
+
+def test_finding_n1_and_n2_at_various_intersections():  # finding_n1_and_n2_at_various_intersections_test, :5066: three overlapping glass spheres
+    b = R.SceneBuilder()
+    b.set_camera(8, 8, 1.0, (0, 0, -5), (0, 0, 0))
+    b.set_light((-10, 10, -10), (1, 1, 1))
+    m = R.default_material()
+    b.add_sphere_ext(R.Mat4.scale(2, 2, 2), m, R.material_ext(transparency=1.0, refractive_index=1.5))
+    b.add_sphere_ext(R.Mat4.translate(0, 0, -0.25), m, R.material_ext(transparency=1.0, refractive_index=2.0))
+    b.add_sphere_ext(R.Mat4.translate(0, 0, 0.25), m, R.material_ext(transparency=1.0, refractive_index=2.5))
+    s = b.finish(0)
+    r = O.ray((0, 0, -4), (0, 0, 1))
+    want = [(1.0, 1.5), (1.5, 2.0), (2.0, 2.5), (2.5, 2.5), (2.5, 1.5), (1.5, 1.0)]
+    out = (C.c_double * 2)()
+    for i, w in enumerate(want):
+        assert O.lib().rto_refractive_indices(C.byref(s), C.byref(r), i, out) == 6
+        assert tuple(out) == w, i
