@@ -167,7 +167,12 @@ typedef struct rt_scene {
 enum {
   RT_ACCEL_AUTO = 0,   /* BVH when the scene has one and enough triangles      */
   RT_ACCEL_BRUTE = 1,  /* every ray tests every primitive (the reference's way) */
-  RT_ACCEL_BVH = 2
+  RT_ACCEL_BVH = 2,
+  /* the kernel that keeps the reference's data structures (100-slot intersection list with its slot re-use and
+   * overflow, 4-component tuples; rt_general.hip.inc).  Worlds with planes, cubes, cylinders, patterns or
+   * transparency always use it; for sphere / triangle worlds of up to 65536 objects it can be asked for, e.g. to
+   * cross-check the fast kernels on the GPU at sizes the CPU reference takes minutes for. */
+  RT_ACCEL_REFERENCE = 3
 };
 
 /* One render() call.  The image is camera.hsize x camera.vsize.  With
@@ -194,7 +199,7 @@ typedef struct rt_stats {
   uint64_t sphere_tests;    /* the ray-sphere part of prim_tests                 */
   double kernel_ms;         /* hipEvent time of the trace kernel, this call      */
   int32_t rows_rendered;    /* rows this rank produced                           */
-  int32_t accel_used;       /* RT_ACCEL_BRUTE or RT_ACCEL_BVH                    */
+  int32_t accel_used;       /* RT_ACCEL_BRUTE, RT_ACCEL_BVH or RT_ACCEL_REFERENCE */
 } rt_stats;
 
 /* Bind the process to HIP device `device` and create the stream and events.

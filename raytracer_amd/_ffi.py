@@ -20,6 +20,7 @@ RT_ERR_TOO_LARGE = -6
 RT_ACCEL_AUTO = 0
 RT_ACCEL_BRUTE = 1
 RT_ACCEL_BVH = 2
+RT_ACCEL_REFERENCE = 3
 
 
 class Material(C.Structure):

@@ -131,6 +131,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
+constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
@@ -304,7 +305,7 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
 
 /* A world that needs the general kernel: one object array in world-list order, full 4x4 inverses, materials
  * with their pattern and transparency halves. */
-int upload_general(const rt_scene* sc) {
+int upload_general(const rt_scene* sc, bool only_form) {
   const int ns = sc->n_spheres, nt = sc->n_tris, nsh = sc->n_shapes;
   const long long n_ll = (long long)ns + nt + nsh;
   if (nsh < 0 || (nsh > 0 && !sc->shapes)) return RT_ERR_INVALID;
@@ -385,7 +386,8 @@ int upload_general(const rt_scene* sc) {
   hd.vsize = sc->camera.vsize;
   hd.n_objects = n;
 
-  free_scene();
+  if (only_form) free_scene();
+  else free_general();
   HIP_TRY(hipMalloc((void**)&g.d_gen_scene, sizeof hd));
   HIP_TRY(hipMemcpy(g.d_gen_scene, &hd, sizeof hd, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&g.d_gen_objects, sizeof(GenObject) * objs.size()));
@@ -394,6 +396,7 @@ int upload_general(const rt_scene* sc) {
   HIP_TRY(hipMemcpy(g.d_gen_materials, mats.data(), sizeof(GenMaterial) * mats.size(), hipMemcpyHostToDevice));
   /* a short list when no ray can fill it; otherwise the reference's 100 slots, overflow behaviour included */
   g.gen_list_cap = max_entries <= 32 ? 32 : 100;
+  if (!only_form) return RT_OK; /* the scene also has its sphere / triangle form; RT_ACCEL_REFERENCE selects this one */
   g.general = true;
   g.scene = DevScene{};
   g.scene.hsize = sc->camera.hsize;
@@ -433,7 +436,8 @@ int check_params(const rt_render_params* p) {
   if (p->spp_grid > RT_MAX_SPP_GRID) return RT_ERR_TOO_LARGE;
   if (p->n_ranks < 1 || p->rank < 0 || p->rank >= p->n_ranks) return RT_ERR_INVALID;
   if (p->n_ranks > 1 && p->band_rows < 1) return RT_ERR_INVALID;
-  if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH) return RT_ERR_INVALID;
+  if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH && p->accel != RT_ACCEL_REFERENCE)
+    return RT_ERR_INVALID;
   if (p->accel == RT_ACCEL_BVH && g.scene.n_bvh_nodes == 0 && g.scene.n_tris > 0 && !g.bvh_single_leaf)
     return RT_ERR_NOT_READY;
   return RT_OK;
@@ -452,6 +456,8 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   a.rows = rows;
   a.ablate = p->reserved;
   for (int i = 0; i < RT_MAX_SPP_GRID; ++i) a.sample_off[i] = (i + 0.5) / a.spp_grid; /* ref_harness / oracle: (i + 0.5) / G */
+  const bool general = g.general || p->accel == RT_ACCEL_REFERENCE;
+  if (general && !g.d_gen_scene) return RT_ERR_TOO_LARGE; /* too many objects for the every-ray-every-object kernel */
   bool bvh = g.scene.n_bvh_nodes > 0 && g.scene.n_tris > 0;
   if (p->accel == RT_ACCEL_BRUTE) bvh = false;
   if (p->accel == RT_ACCEL_AUTO && g.scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
@@ -462,7 +468,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
     if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     int n_blocks = 0;
-    if (g.general) {
+    if (general) {
       a.n_heavy = (int)n_tiles;
       a.light_per_block = 1;
       n_blocks = (int)n_tiles;
@@ -475,14 +481,14 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
     (void)n_tiles;
     dim3 grid((unsigned)n_blocks);
     if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
-    if (g.general) launch_general(count, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
+    if (general) launch_general(count, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
     else launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
     if (stats) HIP_TRY(hipEventRecord(g.ev1, s));
   }
   if (stats) {
     stats->rows_rendered = rows;
-    stats->accel_used = bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE;
+    stats->accel_used = general ? RT_ACCEL_REFERENCE : (bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE);
     if (rows > 0) {
       HIP_TRY(hipEventSynchronize(g.ev1));
       float ms = 0.f;
@@ -550,7 +556,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       (sc->n_tris && (!sc->tri_soa || !sc->tri_material || !sc->tri_order)))
     return RT_ERR_INVALID;
   if ((long long)sc->camera.hsize * sc->camera.vsize > (1ll << 31) / 3) return RT_ERR_TOO_LARGE;
-  if (sc->n_shapes != 0 || sc->materials_ext) return upload_general(sc);
+  if (sc->n_shapes != 0 || sc->materials_ext) return upload_general(sc, true);
   const int ns = sc->n_spheres, nt = sc->n_tris;
   const int n_prims = ns + nt;
 
@@ -733,6 +739,11 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if (!g.d_scene) HIP_TRY(hipMalloc((void**)&g.d_scene, sizeof(DevScene)));
   HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
   g.have_scene = true;
+  /* small worlds also get the general kernel's form, for RT_ACCEL_REFERENCE */
+  if (n_prims <= kMaxReferenceObjects) {
+    const int rc = upload_general(sc, false);
+    if (rc != RT_OK) return rc;
+  }
   return RT_OK;
 }
 

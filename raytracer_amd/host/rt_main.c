@@ -4,9 +4,10 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
- *                 [--host-ppm]
+ *                 [--host-ppm] [--reference-list]
  *
- * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres.
+ * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres, refraction,
+ * world_with_plane, dual_spheres.
  * With no options it does what the reference binary does: lighthouse, 300x300, ./canvas.ppm,
  * reading ./lighthouse.obj.  The P3 text of the file is formatted on the GPU (rt_hip_render_ppm) unless
  * --host-ppm asks for the C writer rt_write_ppm; both emit the bytes of write_canvas_to_file (:1333).
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--brute")) accel = RT_ACCEL_BRUTE;
     else if (!strcmp(argv[i], "--bvh")) accel = RT_ACCEL_BVH;
+    else if (!strcmp(argv[i], "--reference-list")) accel = RT_ACCEL_REFERENCE;
     else if (!strcmp(argv[i], "--host-ppm")) host_ppm = 1;
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
@@ -100,7 +102,7 @@ int main(int argc, char** argv) {
   printf("%llu rays (%llu primary, %llu shadow, %llu reflected), kernel %.3f ms, %.1f Mrays/s, %s\n", rays,
          (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,
          (unsigned long long)st.rays_secondary, st.kernel_ms, rays / (st.kernel_ms * 1e3),
-         st.accel_used == RT_ACCEL_BVH ? "BVH" : "brute force");
+         st.accel_used == RT_ACCEL_BVH ? "BVH" : (st.accel_used == RT_ACCEL_REFERENCE ? "reference list" : "brute force"));
   printf("Writing Canvas To File\n");
   if (host_ppm) {
     if ((rc = rt_write_ppm(out, buf, W, H)) != RT_OK) return fail("rt_write_ppm", rc);

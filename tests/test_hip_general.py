@@ -143,3 +143,19 @@ def test_long_lists_use_the_100_slot_list(hip):
     assert O.probe().max_list == 40
     assert st.rays == ost.rays
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("scene,w,h,tr,sr", [("cube", 1920, 1080, 0.0, 0.0), ("spheres", 1920, 1080, 0.0, 0.0),
+                                              ("cube_spheres", 1280, 720, 0.3, 0.3), ("lighthouse", 960, 540, 0.3, 0.0)])
+def test_fast_kernels_equal_the_list_kernel_on_the_gpu(hip, scene, w, h, tr, sr):
+    """RT_ACCEL_REFERENCE runs the kernel that keeps the reference's 100-slot list, stable sort and 4-component
+    tuples on a sphere / triangle world: the running-minimum kernels (exhaustive and BVH) must give the same bytes and
+    ray counts at sizes the CPU reference needs minutes for."""
+    hip.upload(R.stock_scene(scene, w, h, tr, sr))
+    ref, rst = hip.render(accel=R._ffi.RT_ACCEL_REFERENCE, count_rays=True)
+    assert rst.accel_used == R._ffi.RT_ACCEL_REFERENCE
+    for accel in (R._ffi.RT_ACCEL_BRUTE, R._ffi.RT_ACCEL_BVH):
+        got, st = hip.render(accel=accel, count_rays=True)
+        assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (rst.rays_primary, rst.rays_shadow, rst.rays_secondary)
+        assert_image_parity(got, ref, f"{scene} accel {accel}")
+        assert np.array_equal(got, ref)
