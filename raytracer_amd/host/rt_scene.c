@@ -227,7 +227,6 @@ static int intern_material_ext(rt_scene_builder* b, const rt_material* m, const 
   if (!grow((void**)&b->exts, &b->cap_exts, b->n_materials + 1, sizeof e)) return -1;
   b->materials[b->n_materials] = *m;
   b->exts[b->n_materials] = e;
-  if (x) b->any_ext = 1;
   return b->n_materials++;
 }
 static int intern_material(rt_scene_builder* b, const rt_material* m) { return intern_material_ext(b, m, NULL, NULL); }
@@ -506,6 +505,12 @@ int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out) {
     }
     out->n_shapes = b->n_shapes;
     out->shapes = b->out_shapes;
+  }
+  /* the second half of the materials travels only when some material needs it (the fast kernels do not read it) */
+  b->any_ext = 0;
+  for (int i = 0; i < b->n_materials; ++i) {
+    const rt_material_ext* x = &b->exts[i].x;
+    if (x->pattern_type != RT_PATTERN_NONE || x->transparency != 0.0 || x->refractive_index != 1.0) b->any_ext = 1;
   }
   if (b->any_ext && b->n_materials > 0) {
     b->out_exts = malloc(sizeof(rt_material_ext) * (size_t)b->n_materials);

@@ -164,3 +164,11 @@ def test_unsupported_scenes_are_rejected():
     b2.set_light((0, 0, 0), (1, 1, 1))
     with pytest.raises(RuntimeError):
         b2.finish(0)  # no camera
+
+
+def test_plain_worlds_do_not_carry_the_material_extension():
+    """Overriding reflectivity must not turn a sphere / triangle world into one for the general kernel."""
+    for name, tr, sr in (("cube", 0.3, 0.0), ("cube_spheres", 0.3, 0.3), ("spheres", 0.0, 0.5)):
+        s = R.stock_scene(name, 32, 24, tr, sr)
+        assert not s.materials_ext and s.n_shapes == 0
+    assert R.stock_scene("refraction", 32, 24).materials_ext

@@ -156,6 +156,7 @@ def test_fast_kernels_equal_the_list_kernel_on_the_gpu(hip, scene, w, h, tr, sr)
     assert rst.accel_used == R._ffi.RT_ACCEL_REFERENCE
     for accel in (R._ffi.RT_ACCEL_BRUTE, R._ffi.RT_ACCEL_BVH):
         got, st = hip.render(accel=accel, count_rays=True)
+        assert st.accel_used != R._ffi.RT_ACCEL_REFERENCE  # reflective materials alone must not select the list kernel
         assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (rst.rays_primary, rst.rays_shadow, rst.rays_secondary)
         assert_image_parity(got, ref, f"{scene} accel {accel}")
         assert np.array_equal(got, ref)

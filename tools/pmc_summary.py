@@ -6,7 +6,8 @@ acc = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "rt_trace_kernel" not in row.get("Kernel_Name", ""):
+        name = row.get("Kernel_Name", "")
+        if "rt_trace_kernel" not in name and "rt_general_kernel" not in name:
             continue
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
