@@ -89,40 +89,46 @@ static int build_range(build_t* B, int first, int count) {
     B->nodes[me].right = -count;
     return me;
   }
-  /* binned SAH along the widest centroid axis */
-  box_t bin_box[NBINS];
-  int bin_cnt[NBINS];
-  for (int i = 0; i < NBINS; ++i) { box_empty(&bin_box[i]); bin_cnt[i] = 0; }
-  const double scale = NBINS / ext;
-  for (int i = first; i < first + count; ++i) {
-    int bi = (int)((B->prims[i].c[axis] - cb.lo[axis]) * scale);
-    if (bi < 0) bi = 0;
-    if (bi >= NBINS) bi = NBINS - 1;
-    bin_cnt[bi]++;
-    box_grow(&bin_box[bi], &B->prims[i].b);
-  }
-  double right_area[NBINS];
-  int right_cnt[NBINS];
-  box_t acc;
-  box_empty(&acc);
-  int cnt = 0;
-  for (int i = NBINS - 1; i > 0; --i) {
-    if (bin_cnt[i]) box_grow(&acc, &bin_box[i]);
-    cnt += bin_cnt[i];
-    right_area[i] = box_area(&acc);
-    right_cnt[i] = cnt;
-  }
-  box_empty(&acc);
-  cnt = 0;
-  int best = -1;
+  /* binned SAH: the cheapest of the NBINS - 1 splits of each of the three axes */
+  int best = -1, best_axis = axis;
   double best_cost = DBL_MAX;
-  for (int i = 1; i < NBINS; ++i) { /* split between bin i-1 and bin i */
-    if (bin_cnt[i - 1]) box_grow(&acc, &bin_box[i - 1]);
-    cnt += bin_cnt[i - 1];
-    if (cnt == 0 || right_cnt[i] == 0) continue;
-    double cost = box_area(&acc) * cnt + right_area[i] * right_cnt[i];
-    if (cost < best_cost) { best_cost = cost; best = i; }
+  for (int ax = 0; ax < 3; ++ax) {
+    const double ext_a = cb.hi[ax] - cb.lo[ax];
+    if (!(ext_a > 0.0)) continue;
+    box_t bin_box[NBINS];
+    int bin_cnt[NBINS];
+    for (int i = 0; i < NBINS; ++i) { box_empty(&bin_box[i]); bin_cnt[i] = 0; }
+    const double scale_a = NBINS / ext_a;
+    for (int i = first; i < first + count; ++i) {
+      int bi = (int)((B->prims[i].c[ax] - cb.lo[ax]) * scale_a);
+      if (bi < 0) bi = 0;
+      if (bi >= NBINS) bi = NBINS - 1;
+      bin_cnt[bi]++;
+      box_grow(&bin_box[bi], &B->prims[i].b);
+    }
+    double right_area[NBINS];
+    int right_cnt[NBINS];
+    box_t acc;
+    box_empty(&acc);
+    int cnt = 0;
+    for (int i = NBINS - 1; i > 0; --i) {
+      if (bin_cnt[i]) box_grow(&acc, &bin_box[i]);
+      cnt += bin_cnt[i];
+      right_area[i] = box_area(&acc);
+      right_cnt[i] = cnt;
+    }
+    box_empty(&acc);
+    cnt = 0;
+    for (int i = 1; i < NBINS; ++i) { /* split between bin i-1 and bin i */
+      if (bin_cnt[i - 1]) box_grow(&acc, &bin_box[i - 1]);
+      cnt += bin_cnt[i - 1];
+      if (cnt == 0 || right_cnt[i] == 0) continue;
+      double cost = box_area(&acc) * cnt + right_area[i] * right_cnt[i];
+      if (cost < best_cost) { best_cost = cost; best = i; best_axis = ax; }
+    }
   }
+  axis = best_axis;
+  const double scale = NBINS / (cb.hi[axis] - cb.lo[axis]);
   int mid;
   if (best < 0) {
     mid = first + count / 2;
