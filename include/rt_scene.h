@@ -74,6 +74,8 @@ int rt_scene_add_shape(rt_scene_builder* b, int type, const double transform[16]
                        int closed);
 int rt_scene_add_triangle(rt_scene_builder* b, const double p1[3], const double p2[3], const double p3[3],
                           const rt_material* m);
+int rt_scene_add_triangle_ext(rt_scene_builder* b, const double p1[3], const double p2[3], const double p3[3],
+                              const rt_material* m, const rt_material_ext* x, const double* pattern_transform);
 /* n triangles, 9 floats each (p1 p2 p3), widened to double as load_model_file does (RayTracer.c:1657-1669) */
 int rt_scene_add_triangles_f32(rt_scene_builder* b, const float* xyz9, int n, const rt_material* m);
 /* `v` and `f` records of a Wavefront OBJ text; 3- or 4-vertex faces (quads fan-split, RayTracer.c:1696-1697) */

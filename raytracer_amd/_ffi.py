@@ -164,6 +164,7 @@ def host_lib():
         L.rt_scene_add_sphere_ext.argtypes = [C.c_void_p, _dp, C.POINTER(Material), C.POINTER(MaterialExt), _dp]
         L.rt_scene_add_shape.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(Material), C.POINTER(MaterialExt), _dp,
                                          C.c_double, C.c_double, C.c_int]
+        L.rt_scene_add_triangle_ext.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(Material), C.POINTER(MaterialExt), _dp]
         L.rt_material_ext_default.restype = MaterialExt
         L.rt_scene_add_triangle.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(Material)]
         L.rt_scene_add_triangles_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(Material)]

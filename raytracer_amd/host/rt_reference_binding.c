@@ -60,7 +60,7 @@ int rt_render_hip(camera* c, world* w) {
     } else if (sp->type == TRIANGLE) {
       const double p1[3] = {sp->p1.x, sp->p1.y, sp->p1.z}, p2[3] = {sp->p2.x, sp->p2.y, sp->p2.z},
                    p3[3] = {sp->p3.x, sp->p3.y, sp->p3.z};
-      rc = plain ? rt_scene_add_triangle(b, p1, p2, p3, &m) : RT_ERR_UNSUPPORTED;
+      rc = rt_scene_add_triangle_ext(b, p1, p2, p3, &m, xp, pt);
     } else if (sp->type == PLANE || sp->type == CUBE) {
       rc = rt_scene_add_shape(b, sp->type == PLANE ? RT_SHAPE_PLANE : RT_SHAPE_CUBE, &sp->transform[0][0], &m, xp, pt,
                               -INFINITY, INFINITY, 0);

@@ -229,7 +229,6 @@ static int intern_material_ext(rt_scene_builder* b, const rt_material* m, const 
   b->exts[b->n_materials] = e;
   return b->n_materials++;
 }
-static int intern_material(rt_scene_builder* b, const rt_material* m) { return intern_material_ext(b, m, NULL, NULL); }
 
 /* position in the world list of the object being appended (add_shape_to_world, RayTracer.c:1078) */
 static int next_order(rt_scene_builder* b, const double* transform) {
@@ -313,9 +312,14 @@ int rt_scene_add_shape(rt_scene_builder* b, int type, const double transform[16]
 
 int rt_scene_add_triangle(rt_scene_builder* b, const double p1[3], const double p2[3], const double p3[3],
                           const rt_material* m) {
+  return rt_scene_add_triangle_ext(b, p1, p2, p3, m, NULL, NULL);
+}
+
+int rt_scene_add_triangle_ext(rt_scene_builder* b, const double p1[3], const double p2[3], const double p3[3],
+                              const rt_material* m, const rt_material_ext* x, const double* pattern_transform) {
   if (!b || !p1 || !p2 || !p3) return RT_ERR_INVALID;
   if (!grow((void**)&b->tris, &b->cap_tris, b->n_tris + 1, sizeof(tri_rec))) return RT_ERR_INVALID;
-  int mi = intern_material(b, m);
+  int mi = intern_material_ext(b, m, x, pattern_transform);
   if (mi < 0) return RT_ERR_INVALID;
   tri_rec* t = &b->tris[b->n_tris++];
   memcpy(t->p1, p1, sizeof t->p1);

@@ -151,9 +151,11 @@ class SceneBuilder:
         pt = _m16(pattern_transform) if pattern_transform is not None else None
         return check(self._L.rt_scene_add_shape(self._b, ty, _m16(t), m, x, pt, minimum, maximum, int(closed)), "add_shape")
 
-    def add_triangle(self, p1, p2, p3, material=None):
+    def add_triangle(self, p1, p2, p3, material=None, ext=None, pattern_transform=None):
         m = C.byref(material) if material is not None else None
-        return check(self._L.rt_scene_add_triangle(self._b, _d3(p1), _d3(p2), _d3(p3), m), "add_triangle")
+        x = C.byref(ext) if ext is not None else None
+        pt = _m16(pattern_transform) if pattern_transform is not None else None
+        return check(self._L.rt_scene_add_triangle_ext(self._b, _d3(p1), _d3(p2), _d3(p3), m, x, pt), "add_triangle")
 
     def add_triangles_f32(self, xyz9, material=None):
         a = np.ascontiguousarray(xyz9, dtype=np.float32).reshape(-1, 9)

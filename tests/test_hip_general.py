@@ -98,6 +98,9 @@ def random_general_world(seed, w, h):
         c = rng.uniform(-2, 2, 3) + np.array([0, 1.5, 1.0])
         p = (c + rng.uniform(-0.8, 0.8, (3, 3))).astype(np.float32).astype(np.float64)
         b.add_triangle(p[0], p[1], p[2], mat(reflective=0.4))
+    p = np.array([[-3, 0.2, 2.5], [3, 0.2, 2.5], [0, 3.5, 2.0]], dtype=np.float32).astype(np.float64)
+    b.add_triangle(p[0], p[1], p[2], mat(diffuse=0.3), material_ext(transparency=0.6, refractive_index=1.1))
+    b.add_triangle(p[0] + [0, 0, 1], p[2] + [0, 0, 1], p[1] + [0, 0, 1], mat(), pat(P.RT_PATTERN_STRIPE), Mat4.scale(0.3, 0.3, 0.3))
     return b.finish(0)
 
 
