@@ -63,7 +63,7 @@ def algorithmic_flops(st):
 
 
 def side_measurements(hip, dev, steps=100):
-    """Context for the headline: the other BASELINE scenes at 1920x1080 on this GPU, kernel time from HIP events."""
+    """Context for the headline: the other benchmark scenes at 1920x1080 on this GPU, kernel time from HIP events."""
     out = {}
     buf = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     for name, scene, tr, accel in (("spheres_1080p", "spheres", 0.0, R._ffi.RT_ACCEL_AUTO),

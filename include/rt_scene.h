@@ -7,7 +7,7 @@
  * A host that already holds the reference's `world`/`camera` structs needs
  * only rt_scene_add_* and rt_scene_set_camera_view: it passes
  * shape.transform, shape.p1..p3, shape.material and camera.view_transform
- * straight through (INTEGRATION.md shows the loop).
+ * straight through (raytracer_amd/host/rt_reference_binding.c is that loop).
  *
  * Reference counterparts (RayTracer/RayTracer.c):
  *   rt_mat4_mul            mat4x4_mul_in_place   :405

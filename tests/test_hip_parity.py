@@ -69,7 +69,7 @@ def test_reference_images_300(hip, manifest, name, accel):
 
 @pytest.mark.parametrize("name", ["lighthouse_1080p", "cube_1080p", "spheres_1080p"])
 def test_reference_images_1080p(hip, manifest, name):
-    """Full BASELINE sizes against the reference's 1920x1080 images."""
+    """Full benchmark sizes against the reference's 1920x1080 images."""
     e = manifest[name]
     hip.upload(scene_for(e))
     got, st = hip.render(count_rays=True)
@@ -160,7 +160,7 @@ def test_errors_are_returned_not_raised_by_abort(hip, manifest):
         hip.render(accel=R._ffi.RT_ACCEL_BVH)
 
 
-# ---- BASELINE configs 4 and 5 at their full sizes ----
+# ---- benchmark configurations 4 and 5 at their full sizes ----
 def oracle_rows(scene, height, every, **kw):
     """Rows y = 0, every, 2*every, ... from the CPU oracle (band_rows = 1, rank 0 of `every` ranks)."""
     rows, st = O.render_rgb(scene, n_ranks=every, band_rows=1, rank=0, **kw)

@@ -87,7 +87,7 @@ def test_render_ppm_hashes_to_the_reference_file(hip, manifest, name):
 
 
 def test_8k_frame_text(hip):
-    """BASELINE's largest frame (7680x4320): length from the digit counts, content against the host writer."""
+    """The largest benchmark frame (7680x4320): length from the digit counts, content against the host writer."""
     h, w = 4320, 7680
     rng = np.random.default_rng(8)
     img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
