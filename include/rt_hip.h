@@ -211,6 +211,23 @@ int rt_hip_init(int device);
  * stays resident until the next upload. */
 int rt_hip_upload_scene(const rt_scene* scene);
 
+/* What rt_hip_build_bvh_device made. */
+typedef struct rt_bvh_device_info {
+  int32_t n_nodes;  /* inner nodes in device memory (0: the mesh fits one leaf) */
+  int32_t depth;    /* inner nodes on the longest root-to-leaf path              */
+  double build_ms;  /* hipEvent time of the whole build                          */
+} rt_bvh_device_info;
+
+/* Build a bounding volume hierarchy on the device over the triangles of the
+ * uploaded scene (Morton order + radix tree) and use it from the next render
+ * on, in place of whatever tree the scene came with: for meshes too large or
+ * too short-lived for the host builder of rt_scene_finish.  leaf_size in 1..7.
+ * The reference has no counterpart (intersect_world, RayTracer.c:1043, tests
+ * every object); as with the host tree the image does not depend on it.
+ * RT_ERR_TOO_LARGE if the tree would be deeper than the walk's stack, in which
+ * case the scene is left as it was.  info may be NULL. */
+int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info);
+
 /* render(c, &w) + color_convert: fills rgb_out (host memory) with this rank's
  * rows, 3 bytes per pixel, row-major (y outer, x inner: the order in which
  * write_canvas_to_file walks the canvas, RayTracer.c:1337-1338).

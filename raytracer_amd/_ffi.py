@@ -123,6 +123,10 @@ class RenderParams(C.Structure):
     ]
 
 
+class BvhDeviceInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("depth", C.c_int32), ("build_ms", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64),
@@ -211,6 +215,7 @@ def hip_lib():
         L = C.CDLL(path)
         L.rt_hip_init.argtypes = [C.c_int]
         L.rt_hip_upload_scene.argtypes = [C.POINTER(Scene)]
+        L.rt_hip_build_bvh_device.argtypes = [C.c_int, C.POINTER(BvhDeviceInfo)]
         L.rt_hip_render.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_device.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_f64.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
@@ -237,6 +242,7 @@ def hip_lib():
 HIP_EXPORTS = [
     "rt_hip_init",
     "rt_hip_upload_scene",
+    "rt_hip_build_bvh_device",
     "rt_hip_render",
     "rt_hip_render_device",
     "rt_hip_render_f64",

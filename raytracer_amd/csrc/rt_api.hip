@@ -19,6 +19,7 @@
 #include "rt_kernels.hip.inc"
 #include "rt_general.hip.inc"
 #include "rt_ppm.hip.inc"
+#include "rt_lbvh.hip.inc"
 
 namespace {
 
@@ -45,6 +46,7 @@ struct Context {
   void* d_bvh = nullptr;
   DevScene* d_scene = nullptr; /* device copy of `scene` */
   double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
+  double box_pad = 0.0; /* what every single-precision box is grown by */
   /* tile order of the last plan and the parameters it was made for */
   int32_t* d_tile_list = nullptr;
   size_t tile_list_cap = 0;
@@ -510,6 +512,21 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   return RT_OK;
 }
 
+
+/* device allocations of one build: freed on every exit unless handed over */
+struct BuildBuffers {
+  std::vector<void*> owned;
+  ~BuildBuffers() { for (void* p : owned) if (p) (void)hipFree(p); }
+  template <class T> bool get(T** out, size_t count) {
+    void* p = nullptr;
+    if (!hip_ok(hipMalloc(&p, sizeof(T) * (count ? count : 1)), "hipMalloc (bvh build)")) return false;
+    owned.push_back(p);
+    *out = (T*)p;
+    return true;
+  }
+  void release(void* p) { for (void*& q : owned) if (q == p) q = nullptr; }
+};
+
 }  // namespace
 
 extern "C" {
@@ -723,6 +740,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     d.box_hi[c] = nt ? std::nextafterf((float)(bhi[c] + pad), INFINITY) : 0.f;
   }
   for (int c = 0; c < 3; ++c) { g.mesh_lo[c] = blo[c] - pad; g.mesh_hi[c] = bhi[c] + pad; }
+  g.box_pad = pad;
   g.scene_serial++;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
   memcpy(d.light_int, sc->light.intensity, sizeof d.light_int);
@@ -744,6 +762,119 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     const int rc = upload_general(sc, false);
     if (rc != RT_OK) return rc;
   }
+  return RT_OK;
+}
+
+int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
+  if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
+  if (leaf_size < 1 || leaf_size > 7) return RT_ERR_INVALID;
+  if (g.general) return RT_ERR_UNSUPPORTED; /* worlds of the general kernel walk the reference's list */
+  const int n = g.scene.n_tris;
+  if (n >= (1 << 27)) return RT_ERR_TOO_LARGE;
+  if (info) memset(info, 0, sizeof *info);
+  if (n <= leaf_size) { /* nothing to walk: the exhaustive loop is the walk */
+    if (g.d_bvh) (void)hipFree(g.d_bvh);
+    g.d_bvh = nullptr;
+    g.scene.n_bvh_nodes = 0;
+    g.scene.bvh_depth = 0;
+    g.bvh_single_leaf = n > 0;
+    HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
+    g.scene_serial++;
+    return RT_OK;
+  }
+  BuildBuffers b;
+  unsigned long long *keys, *keys_sorted;
+  unsigned *index, *index_sorted, *visits, *walked, *slot;
+  DevTri* tris_out;
+  DevTriPrimary* prim_out;
+  double* normals_out;
+  float *leaf_lo, *leaf_hi, *node_lo, *node_hi;
+  int *left, *right, *range_lo, *range_hi, *parent_of_node, *parent_of_leaf, *node_depth;
+  DevBvh2* nodes;
+  const size_t nn = (size_t)n, ni = nn - 1;
+  if (!b.get(&keys, nn) || !b.get(&keys_sorted, nn) || !b.get(&index, nn) || !b.get(&index_sorted, nn) ||
+      !b.get(&visits, ni) || !b.get(&walked, ni) || !b.get(&slot, ni) || !b.get(&tris_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) ||
+      !b.get(&leaf_lo, 3 * nn) || !b.get(&leaf_hi, 3 * nn) || !b.get(&node_lo, 3 * ni) || !b.get(&node_hi, 3 * ni) ||
+      !b.get(&left, ni) || !b.get(&right, ni) || !b.get(&range_lo, ni) || !b.get(&range_hi, ni) ||
+      !b.get(&parent_of_node, ni) || !b.get(&parent_of_leaf, nn) || !b.get(&node_depth, ni) || !b.get(&nodes, ni))
+    return RT_ERR_HIP;
+  size_t sort_bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, index, index_sorted, n, 0, 63, g.stream));
+  size_t scan_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, walked, slot, (int)ni, g.stream));
+  unsigned char* sort_space; /* both library calls work in it, one after the other */
+  const size_t space_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  if (!b.get(&sort_space, space_bytes)) return RT_ERR_HIP;
+
+  double scale[3];
+  for (int c = 0; c < 3; ++c) {
+    const double extent = g.mesh_hi[c] - g.mesh_lo[c];
+    scale[c] = extent > 0.0 ? 2097152.0 / extent : 0.0;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return RT_ERR_HIP; }
+  const dim3 per_tri((unsigned)((nn + LBVH_THREADS - 1) / LBVH_THREADS)), per_node((unsigned)((ni + LBVH_THREADS - 1) / LBVH_THREADS));
+  hipStream_t s = g.stream;
+  hipError_t e = hipEventRecord(e0, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lbvh_keys_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)g.d_tris, n, g.mesh_lo[0], g.mesh_lo[1],
+                       g.mesh_lo[2], scale[0], scale[1], scale[2], keys, index);
+    e = hipcub::DeviceRadixSort::SortPairs(sort_space, sort_bytes, keys, keys_sorted, index, index_sorted, n, 0, 63, s);
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lbvh_gather_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)g.d_tris,
+                       (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const unsigned*)index_sorted, n,
+                       g.box_pad, tris_out, prim_out, normals_out, leaf_lo, leaf_hi);
+    hipLaunchKernelGGL(lbvh_hierarchy_kernel, per_node, dim3(LBVH_THREADS), 0, s, (const unsigned long long*)keys_sorted, n, leaf_size,
+                       walked, left, right, range_lo, range_hi, parent_of_node, parent_of_leaf);
+    e = hipMemsetAsync(visits, 0, sizeof(unsigned) * ni, s);
+  }
+  if (e == hipSuccess) {
+    size_t bytes = space_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(sort_space, bytes, walked, slot, (int)ni, s);
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lbvh_fit_kernel, dim3((unsigned)((nn + LBVH_FIT_THREADS - 1) / LBVH_FIT_THREADS)), dim3(LBVH_FIT_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,
+                       (const int*)range_lo, (const int*)range_hi, (const int*)parent_of_node, (const int*)parent_of_leaf,
+                       (const float*)leaf_lo, (const float*)leaf_hi, node_lo, node_hi, node_depth, visits);
+    hipLaunchKernelGGL(lbvh_emit_kernel, per_node, dim3(LBVH_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,
+                       (const int*)range_lo, (const int*)range_hi, (const float*)leaf_lo, (const float*)leaf_hi,
+                       (const float*)node_lo, (const float*)node_hi, (const unsigned*)walked, (const unsigned*)slot, nodes);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipEventRecord(e1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  int depth = 0;
+  unsigned last_slot = 0, last_walked = 0;
+  if (e == hipSuccess) e = hipMemcpy(&depth, node_depth, sizeof depth, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&last_slot, slot + (ni - 1), sizeof last_slot, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&last_walked, walked + (ni - 1), sizeof last_walked, hipMemcpyDeviceToHost);
+  const int n_walked = (int)(last_slot + last_walked);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!hip_ok(e, "device BVH build")) return RT_ERR_HIP;
+  if (depth < 1 || depth > RT_BVH_STACK) {
+    snprintf(g_err, sizeof g_err, "device BVH is %d levels deep; the walk's stack holds %d", depth, RT_BVH_STACK);
+    return RT_ERR_TOO_LARGE;
+  }
+  /* hand over: the sorted triangle arrays and the nodes replace the scene's */
+  if (g.d_tris) (void)hipFree(g.d_tris);
+  if (g.d_tri_primary) (void)hipFree(g.d_tri_primary);
+  if (g.d_normals) (void)hipFree(g.d_normals);
+  if (g.d_bvh) (void)hipFree(g.d_bvh);
+  g.d_tris = tris_out; b.release(tris_out);
+  g.d_tri_primary = prim_out; b.release(prim_out);
+  g.d_normals = normals_out; b.release(normals_out);
+  g.d_bvh = nodes; b.release(nodes);
+  g.scene.n_bvh_nodes = n_walked;
+  g.scene.bvh_depth = depth;
+  g.bvh_single_leaf = false;
+  HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
+  g.scene_serial++;
+  if (info) { info->n_nodes = n_walked; info->depth = depth; info->build_ms = ms; }
   return RT_OK;
 }
 

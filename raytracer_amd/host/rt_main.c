@@ -4,13 +4,14 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
- *                 [--host-ppm] [--reference-list]
+ *                 [--host-ppm] [--reference-list] [--device-bvh]
  *
  * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres, refraction,
  * world_with_plane, dual_spheres.
  * With no options it does what the reference binary does: lighthouse, 300x300, ./canvas.ppm,
  * reading ./lighthouse.obj.  The P3 text of the file is formatted on the GPU (rt_hip_render_ppm) unless
  * --host-ppm asks for the C writer rt_write_ppm; both emit the bytes of write_canvas_to_file (:1333).
+ * --device-bvh skips the host's SAH tree and builds one on the GPU (rt_hip_build_bvh_device).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,7 +37,7 @@ int main(int argc, char** argv) {
   const char* obj = "lighthouse.obj";
   const char* tris_f32 = NULL;
   const char* out = "canvas.ppm";
-  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
+  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
   double tri_refl = 0.0, sph_refl = 0.0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--bvh")) accel = RT_ACCEL_BVH;
     else if (!strcmp(argv[i], "--reference-list")) accel = RT_ACCEL_REFERENCE;
     else if (!strcmp(argv[i], "--host-ppm")) host_ppm = 1;
+    else if (!strcmp(argv[i], "--device-bvh")) device_bvh = 1;
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -78,10 +80,15 @@ int main(int argc, char** argv) {
   }
   if (tri_refl != 0.0 || sph_refl != 0.0) rt_scene_set_reflective(b, tri_refl, sph_refl);
   rt_scene s;
-  if ((rc = rt_scene_finish(b, 4, &s)) != RT_OK) return fail("rt_scene_finish", rc);
+  if ((rc = rt_scene_finish(b, device_bvh ? 0 : 4, &s)) != RT_OK) return fail("rt_scene_finish", rc);
 
   if ((rc = rt_hip_init(device)) != RT_OK) return fail("rt_hip_init", rc);
   if ((rc = rt_hip_upload_scene(&s)) != RT_OK) return fail("rt_hip_upload_scene", rc);
+  if (device_bvh) {
+    rt_bvh_device_info info;
+    if ((rc = rt_hip_build_bvh_device(4, &info)) != RT_OK) return fail("rt_hip_build_bvh_device", rc);
+    printf("BVH built on the device: %d nodes, depth %d, %.3f ms\n", info.n_nodes, info.depth, info.build_ms);
+  }
 
   const size_t cap = host_ppm ? (size_t)W * H * 3 : rt_hip_ppm_capacity(W, H);
   uint8_t* buf = malloc(cap ? cap : 1); /* the 8-bit image, or the text of the file */

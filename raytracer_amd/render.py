@@ -45,6 +45,12 @@ class HipRenderer:
         self.width, self.height = scene.camera.hsize, scene.camera.vsize
         return self
 
+    def build_bvh_device(self, leaf_size=4):
+        """Replace the scene's BVH by one built on the GPU; returns (inner nodes, depth, build ms)."""
+        info = _ffi.BvhDeviceInfo()
+        _check(self._L.rt_hip_build_bvh_device(int(leaf_size), C.byref(info)), "rt_hip_build_bvh_device")
+        return info.n_nodes, info.depth, info.build_ms
+
     def scene_counts(self):
         """(spheres, triangles) of the uploaded scene."""
         return (self._scene.n_spheres, self._scene.n_tris) if self._scene is not None else (0, 0)
