@@ -387,6 +387,8 @@ int upload_general(const rt_scene* sc, bool only_form) {
   hd.hsize = sc->camera.hsize;
   hd.vsize = sc->camera.vsize;
   hd.n_objects = n;
+  for (const GenMaterial& m : mats)
+    if (!(m.transparency == 0.0)) hd.any_transparent = 1; /* the test prepare_computations' walk is behind */
 
   if (only_form) free_scene();
   else free_general();
