@@ -305,8 +305,19 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
   return RT_OK;
 }
 
-/* A world that needs the general kernel: one object array in world-list order, full 4x4 inverses, materials
- * with their pattern and transparency halves. */
+/* Rows 0-2 of an inverse transform for the general kernel, and in place of its last row, which has to be
+ * exactly 0 0 0 1 (every matrix the reference's constructors and inverse() produce for a shape is), the signed
+ * zeros 0.0 * m[3], 0.0 * m[7], 0.0 * m[11] that transform() adds to a transformed vector. */
+bool general_rows(double* dst, const double* inv) {
+  if (inv[12] != 0.0 || inv[13] != 0.0 || inv[14] != 0.0 || inv[15] != 1.0) return false;
+  memcpy(dst, inv, 12 * sizeof(double));
+  for (int r = 0; r < 3; ++r) dst[12 + r] = 0.0 * inv[4 * r + 3];
+  dst[15] = 1.0;
+  return true;
+}
+
+/* A world that needs the general kernel: one object array in world-list order, materials with their pattern and
+ * transparency halves. */
 int upload_general(const rt_scene* sc, bool only_form) {
   const int ns = sc->n_spheres, nt = sc->n_tris, nsh = sc->n_shapes;
   const long long n_ll = (long long)ns + nt + nsh;
@@ -314,6 +325,10 @@ int upload_general(const rt_scene* sc, bool only_form) {
   if (n_ll > (1 << 20)) return RT_ERR_TOO_LARGE; /* every ray visits every object: this path is for small worlds */
   const int n = (int)n_ll;
   if (n > 0 && (sc->n_materials < 1 || !sc->materials)) return RT_ERR_INVALID;
+  {
+    const double* v = sc->camera.inv_view; /* rays leave the camera as (point, vector) */
+    if (v[12] != 0.0 || v[13] != 0.0 || v[14] != 0.0 || v[15] != 1.0) return RT_ERR_UNSUPPORTED;
+  }
   std::vector<GenObject> objs((size_t)(n > 0 ? n : 1));
   std::vector<char> seen((size_t)(n > 0 ? n : 1), 0);
   long long max_entries = 0; /* the most intersections one ray can append */
@@ -330,7 +345,7 @@ int upload_general(const rt_scene* sc, bool only_form) {
     GenObject* o = place(sc->sph_order[i], sc->sph_material[i]);
     if (!o) return RT_ERR_INVALID;
     o->kind = GEN_SPHERE;
-    memcpy(o->m, sc->sph_inv + 16 * (size_t)i, sizeof o->m);
+    if (!general_rows(o->m, sc->sph_inv + 16 * (size_t)i)) return RT_ERR_UNSUPPORTED;
     max_entries += 2;
   }
   for (int i = 0; i < nt; ++i) {
@@ -348,7 +363,7 @@ int upload_general(const rt_scene* sc, bool only_form) {
     else if (sh.type == RT_SHAPE_CUBE) { o->kind = GEN_CUBE; max_entries += 2; }
     else if (sh.type == RT_SHAPE_CYLINDER) { o->kind = GEN_CYLINDER; max_entries += 4; }
     else return RT_ERR_UNSUPPORTED;
-    memcpy(o->m, sh.inv, sizeof o->m);
+    if (!general_rows(o->m, sh.inv)) return RT_ERR_UNSUPPORTED;
     o->minimum = sh.minimum;
     o->maximum = sh.maximum;
     o->closed = sh.closed != 0;
