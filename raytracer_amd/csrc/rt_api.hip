@@ -316,6 +316,62 @@ bool general_rows(double* dst, const double* inv) {
   return true;
 }
 
+/* Largest eigenvalue of the symmetric 3x3 matrix s (closed form, Smith 1961). */
+double largest_eigenvalue_sym3(const double s[3][3]) {
+  const double p1 = s[0][1] * s[0][1] + s[0][2] * s[0][2] + s[1][2] * s[1][2];
+  if (p1 == 0.0) return std::fmax(s[0][0], std::fmax(s[1][1], s[2][2]));
+  const double q = (s[0][0] + s[1][1] + s[2][2]) / 3.0;
+  const double p2 = (s[0][0] - q) * (s[0][0] - q) + (s[1][1] - q) * (s[1][1] - q) + (s[2][2] - q) * (s[2][2] - q) + 2.0 * p1;
+  const double p = std::sqrt(p2 / 6.0);
+  double b[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) b[i][j] = (s[i][j] - (i == j ? q : 0.0)) / p;
+  const double det = b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                     b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+  const double r = std::fmin(1.0, std::fmax(-1.0, det / 2.0));
+  return q + 2.0 * p * std::cos(std::acos(r) / 3.0);
+}
+
+/* World-space bounding sphere of a shape given inverse(transform): a unit sphere or cube (half-diagonal
+ * `reach` = 1 or sqrt 3) or a cylinder segment around `local_centre` on the y axis.  Rounded outwards; radius
+ * INFINITY (= never culled) when the transform is too ill-conditioned to invert here. */
+void general_bound(GenObject* o, const double* inv, double local_y, double reach) {
+  o->bound[0] = o->bound[1] = o->bound[2] = 0.f;
+  o->bound[3] = INFINITY;
+  o->centre_sq = 0.f;
+  const double a[3][3] = {{inv[0], inv[1], inv[2]}, {inv[4], inv[5], inv[6]}, {inv[8], inv[9], inv[10]}};
+  const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                     a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+  if (!(std::fabs(det) > 1e-300) || !std::isfinite(det) || !std::isfinite(reach) || !std::isfinite(local_y)) return;
+  double f[3][3]; /* the forward linear part: inverse of a */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+      f[i][j] = (a[r0][c0] * a[r1][c1] - a[r0][c1] * a[r1][c0]) / det;
+    }
+  /* forward(p) = f * (p - t) with t = the inverse's translation column: inverse(x) = a * x + t */
+  const double local[3] = {0.0 - inv[3], local_y - inv[7], 0.0 - inv[11]};
+  double centre[3], ftf[3][3];
+  for (int i = 0; i < 3; ++i) centre[i] = f[i][0] * local[0] + f[i][1] * local[1] + f[i][2] * local[2];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) ftf[i][j] = f[0][i] * f[0][j] + f[1][i] * f[1][j] + f[2][i] * f[2][j];
+  const double stretch = std::sqrt(std::fmax(0.0, largest_eigenvalue_sym3(ftf))) * (1.0 + 1e-6);
+  /* check the inversion: a * f must be the identity to well below the margins used here */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double v = a[i][0] * f[0][j] + a[i][1] * f[1][j] + a[i][2] * f[2][j];
+      if (!(std::fabs(v - (i == j ? 1.0 : 0.0)) < 1e-9)) return;
+    }
+  const double radius = stretch * reach * (1.0 + 1e-6);
+  const double r2 = radius * radius * (1.0 + 1e-5);
+  double c2 = 0.0;
+  for (int i = 0; i < 3; ++i) c2 += centre[i] * centre[i];
+  if (!std::isfinite(r2) || !std::isfinite(c2) || r2 > 1e30 || c2 > 1e30) return;
+  for (int i = 0; i < 3; ++i) o->bound[i] = (float)centre[i];
+  o->bound[3] = std::nextafterf((float)r2, INFINITY);
+  o->centre_sq = std::nextafterf((float)c2, INFINITY);
+}
+
 /* A world that needs the general kernel: one object array in world-list order, materials with their pattern and
  * transparency halves. */
 int upload_general(const rt_scene* sc, bool only_form) {
@@ -346,12 +402,14 @@ int upload_general(const rt_scene* sc, bool only_form) {
     if (!o) return RT_ERR_INVALID;
     o->kind = GEN_SPHERE;
     if (!general_rows(o->m, sc->sph_inv + 16 * (size_t)i)) return RT_ERR_UNSUPPORTED;
+    general_bound(o, sc->sph_inv + 16 * (size_t)i, 0.0, 1.0);
     max_entries += 2;
   }
   for (int i = 0; i < nt; ++i) {
     GenObject* o = place(sc->tri_order[i], sc->tri_material[i]);
     if (!o) return RT_ERR_INVALID;
     o->kind = GEN_TRIANGLE;
+    o->bound[3] = INFINITY;
     for (int r = 0; r < 12; ++r) o->m[r] = sc->tri_soa[(size_t)r * nt + i];
     max_entries += 1;
   }
@@ -364,6 +422,12 @@ int upload_general(const rt_scene* sc, bool only_form) {
     else if (sh.type == RT_SHAPE_CYLINDER) { o->kind = GEN_CYLINDER; max_entries += 4; }
     else return RT_ERR_UNSUPPORTED;
     if (!general_rows(o->m, sh.inv)) return RT_ERR_UNSUPPORTED;
+    o->bound[3] = INFINITY; /* a plane has none */
+    if (sh.type == RT_SHAPE_CUBE) general_bound(o, sh.inv, 0.0, std::sqrt(3.0));
+    if (sh.type == RT_SHAPE_CYLINDER) { /* the segment minimum..maximum of the unit cylinder, if it is one */
+      const double half = (sh.maximum - sh.minimum) / 2.0;
+      general_bound(o, sh.inv, (sh.maximum + sh.minimum) / 2.0, std::sqrt(1.0 + half * half));
+    }
     o->minimum = sh.minimum;
     o->maximum = sh.maximum;
     o->closed = sh.closed != 0;

@@ -116,6 +116,41 @@ def test_seeded_general_worlds_match_oracle(hip, seed):
     assert (want.sum(axis=2) > 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_silhouettes_of_stretched_shapes_match_oracle(hip, seed):
+    """Spheres, cubes and cylinders scaled by 0.05..2 per axis and rotated: many rays pass close to the edge of a
+    shape, where the kernel's single-precision early-out (line against a bounding sphere) has to stay on the safe
+    side of the reference's discriminant and slab tests.  Canvases agree to the last bits or the test fails."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    b.set_camera(256, 192, 0.8, (0.5, 1.5, -7.0), (0.0, 0.8, 0.0))
+    b.set_light((-5.0, 8.0, -6.0), (1.0, 1.0, 1.0))
+    b.add_shape("plane", Mat4.identity(), default_material())
+    for k in range(15):
+        t = Mat4.translate(rng.uniform(-3, 3), rng.uniform(0.1, 2.5), rng.uniform(-2, 4))
+        r = Mat4.mul(Mat4.rotate_y(rng.uniform(0, math.pi)), Mat4.mul(Mat4.rotate_x(rng.uniform(0, math.pi)),
+                                                                     Mat4.rotate_z(rng.uniform(0, math.pi))))
+        xf = Mat4.mul(Mat4.mul(t, r), Mat4.scale(*rng.uniform(0.05, 2.0, 3)))
+        m = default_material()
+        m.color[:] = list(rng.uniform(0.2, 1.0, 3))
+        m.reflective = float(rng.choice([0.0, 0.5]))
+        ext = material_ext(transparency=0.6, refractive_index=1.3) if k % 5 == 0 else None
+        if k % 3 == 0:
+            b.add_sphere_ext(xf, m, ext)
+        elif k % 3 == 1:
+            b.add_shape("cube", xf, m, ext)
+        else:
+            b.add_shape("cylinder", xf, m, ext, minimum=float(rng.uniform(-2, 0)), maximum=float(rng.uniform(0.1, 2)),
+                        closed=bool(k % 2))
+    s = b.finish(0)
+    hip.upload(s)
+    got, st = hip.render_f64(count_rays=True)
+    want, ost = O.render_f64(s)
+    assert O.probe().list_overflow == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
 def test_supersampled_general_world_and_row_bands(hip):
     s = random_general_world(7, 64, 48)
     hip.upload(s)
