@@ -287,6 +287,8 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
     g.plan_heavy = (int)heavy.size();
     g.plan_tiles = n_tiles;
     heavy.insert(heavy.end(), light.begin(), light.end());
+    /* launches still in flight on other streams read the list that is about to change */
+    HIP_TRY(hipDeviceSynchronize());
     if ((size_t)n_tiles > g.tile_list_cap) {
       if (g.d_tile_list) (void)hipFree(g.d_tile_list);
       g.d_tile_list = nullptr;
