@@ -37,6 +37,22 @@ def test_lighthouse_device_tree_equals_host_tree_and_exhaustive(hip, leaf_size):
     assert np.array_equal(twice, brute)
 
 
+def test_scene_uploaded_without_a_host_tree(hip):
+    """bvh_leaf_size = 0 skips the host builder: RT_ACCEL_BVH is refused until the device build has run."""
+    s = R.stock_scene("lighthouse", 200, 160, bvh_leaf_size=0)
+    assert s.n_bvh_nodes == 0
+    hip.upload(s)
+    brute, sb = hip.render(accel=BRUTE, count_rays=True)
+    with pytest.raises(R.RtError):
+        hip.render(accel=BVH)
+    hip.build_bvh_device(4)
+    tree, st = hip.render(accel=R._ffi.RT_ACCEL_AUTO, count_rays=True)
+    assert st.accel_used == BVH and np.array_equal(tree, brute) and st.rays == sb.rays
+    hip.upload(s)  # a new upload drops the device tree
+    with pytest.raises(R.RtError):
+        hip.render(accel=BVH)
+
+
 @pytest.mark.parametrize("seed,ns,nt,refl", [(2, 0, 40, 0.0), (3, 4, 60, 0.4), (4, 7, 200, 0.8), (7, 3, 2, 0.5)])
 def test_seeded_worlds_device_tree_matches_oracle(hip, seed, ns, nt, refl):
     """Spheres stay outside the tree; canvases agree with the oracle to the last bits."""
