@@ -208,7 +208,9 @@ int rt_hip_init(int device);
 
 /* Copy the flattened world + camera + light to the device.  Replaces the
  * pointer arguments of render(camera*, world*), RayTracer.c:1574: the scene
- * stays resident until the next upload. */
+ * stays resident until the next upload.  A scene with 4096 or more triangles
+ * and no BVH of its own gets one built on the device (see
+ * rt_hip_build_bvh_device); RT_ACCEL_BRUTE still walks every triangle. */
 int rt_hip_upload_scene(const rt_scene* scene);
 
 /* What rt_hip_build_bvh_device made. */

@@ -135,6 +135,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
+constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
 template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT, int KIND>
@@ -844,6 +845,12 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if (n_prims <= kMaxReferenceObjects) {
     const int rc = upload_general(sc, false);
     if (rc != RT_OK) return rc;
+  }
+  /* A mesh this large without a tree would be walked exhaustively by every ray (seconds per frame): build one
+   * here.  A tree that turns out too deep for the walk leaves the scene as it is. */
+  if (!use_bvh && !g.bvh_single_leaf && nt >= kAutoDeviceBvhTris) {
+    const int rc = rt_hip_build_bvh_device(4, nullptr);
+    if (rc != RT_OK && rc != RT_ERR_TOO_LARGE) return rc;
   }
   return RT_OK;
 }

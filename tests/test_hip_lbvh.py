@@ -99,6 +99,19 @@ def test_fewer_triangles_than_a_leaf_and_argument_errors(hip):
         hip.build_bvh_device(4)
 
 
+def test_large_mesh_without_a_tree_gets_one_at_upload(hip):
+    """From 4096 triangles up an upload without a host tree builds the device tree itself."""
+    s = mesh_scene(icosphere(5), 96, 64, reflective=0.25, bvh_leaf_size=0)
+    assert s.n_tris == 20480 and s.n_bvh_nodes == 0
+    hip.upload(s)
+    got, st = hip.render(count_rays=True)
+    assert st.accel_used == BVH and st.prim_tests < st.rays * 100
+    brute, sb = hip.render(accel=BRUTE, count_rays=True)
+    assert sb.accel_used == BRUTE and np.array_equal(got, brute) and st.rays == sb.rays
+    want, _ = O.render_rgb(s)
+    assert np.array_equal(got, want)
+
+
 def test_large_meshes_device_tree(hip):
     """81,920 triangles against the oracle, 1.3 million against the host tree; build times are printed."""
     s = mesh_scene(icosphere(6), 64, 48, reflective=0.25)

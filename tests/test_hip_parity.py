@@ -226,7 +226,7 @@ def icosphere(level):
     return tri.astype(np.float32).reshape(-1, 9)
 
 
-def mesh_scene(tris, w, h, reflective=0.0):
+def mesh_scene(tris, w, h, reflective=0.0, bvh_leaf_size=4):
     from raytracer_amd.scene import SceneBuilder
 
     b = SceneBuilder()
@@ -235,7 +235,7 @@ def mesh_scene(tris, w, h, reflective=0.0):
     b.add_triangles_f32(tris)
     if reflective:
         b.set_reflective(reflective, 0.0)
-    return b.finish(4)
+    return b.finish(bvh_leaf_size)
 
 
 def test_large_mesh_81920_triangles_matches_oracle(hip):
