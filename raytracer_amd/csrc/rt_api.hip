@@ -662,6 +662,10 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   const int n_prims = ns + nt;
 
   /* validate: material indices, list positions form a permutation, affine inverses */
+  {
+    const double* v = sc->camera.inv_view; /* the kernels read rows 0-2: rays leave the camera as (point, vector) */
+    if (v[12] != 0.0 || v[13] != 0.0 || v[14] != 0.0 || v[15] != 1.0) return RT_ERR_UNSUPPORTED;
+  }
   std::vector<char> seen((size_t)(n_prims > 0 ? n_prims : 1), 0);
   for (int i = 0; i < ns; ++i) {
     const double* m = sc->sph_inv + 16 * (size_t)i;

@@ -158,6 +158,26 @@ def test_errors_are_returned_not_raised_by_abort(hip, manifest):
     hip.upload(s)
     with pytest.raises(R.RtError):
         hip.render(accel=R._ffi.RT_ACCEL_BVH)
+    # a projective view or shape transform is refused at upload and the scene on the device stays usable
+    good, _ = hip.render()
+    view = np.eye(4)
+    view[3, 2] = 0.25
+    for kind in ("view", "sphere", "cube"):
+        b = R.SceneBuilder()
+        if kind == "view":
+            b.set_camera_view(32, 24, 0.8, view)
+        else:
+            b.set_camera(32, 24, 0.8, (0.0, 1.0, -5.0), (0.0, 0.0, 0.0))
+        b.set_light((-5.0, 5.0, -5.0), (1.0, 1.0, 1.0))
+        if kind == "cube":
+            b.add_shape("cube", view, R.default_material())
+        else:
+            b.add_sphere(view if kind == "sphere" else None, R.default_material())
+        with pytest.raises(RuntimeError) as err:  # a sphere is refused by rt_scene_finish already, the others by the upload
+            hip.upload(b.finish(0))
+        assert str(R._ffi.RT_ERR_UNSUPPORTED) in str(err.value), kind
+    again, _ = hip.render()
+    assert np.array_equal(again, good)
 
 
 # ---- benchmark configurations 4 and 5 at their full sizes ----
