@@ -70,11 +70,12 @@ struct Context {
   GenMaterial* d_gen_materials = nullptr;
   /* P3 formatter: per-chunk lengths and offsets, library-owned text buffer, pinned word for the length */
   unsigned* d_ppm_len = nullptr;
-  unsigned long long* d_ppm_off = nullptr;
+  unsigned* d_ppm_group = nullptr;
   size_t ppm_chunks_cap = 0;
   unsigned char* d_ppm_text = nullptr;
   size_t d_ppm_text_bytes = 0;
   unsigned long long* h_ppm_total = nullptr; /* pinned */
+  unsigned long long* d_ppm_total_host = nullptr; /* the same word as the device addresses it */
   hipStream_t ppm_stream = nullptr;          /* stream of the last formatting call */
   bool ppm_pending = false;
 };
@@ -992,35 +993,39 @@ int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void
   PpmHeader hd;
   memset(&hd, 0, sizeof hd);
   hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
-  if (!g.h_ppm_total) HIP_TRY(hipHostMalloc((void**)&g.h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
+  if (!g.h_ppm_total) {
+    HIP_TRY(hipHostMalloc((void**)&g.h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&g.d_ppm_total_host, g.h_ppm_total, 0));
+  }
+  /* groups: about a thousand of them keep both the length pass parallel and a chunk's sum over groups short */
+  int per_group = n_chunks / 1024;
+  per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
+  const int n_groups = (n_chunks + per_group - 1) / per_group;
   if ((size_t)n_chunks + 1 > g.ppm_chunks_cap) {
     if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream));
     if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
-    if (g.d_ppm_off) (void)hipFree(g.d_ppm_off);
+    if (g.d_ppm_group) (void)hipFree(g.d_ppm_group);
     g.d_ppm_len = nullptr;
-    g.d_ppm_off = nullptr;
+    g.d_ppm_group = nullptr;
     g.ppm_chunks_cap = 0;
     HIP_TRY(hipMalloc((void**)&g.d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
-    HIP_TRY(hipMalloc((void**)&g.d_ppm_off, sizeof(unsigned long long) * ((size_t)n_chunks + 1)));
+    HIP_TRY(hipMalloc((void**)&g.d_ppm_group, sizeof(unsigned) * ((size_t)n_chunks + 1)));
     g.ppm_chunks_cap = (size_t)n_chunks + 1;
   }
   if (n_chunks > 0) {
-    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, g.d_ppm_len);
-  }
-  hipLaunchKernelGGL(ppm_scan_kernel, dim3(1), dim3(PPM_SCAN_THREADS), 0, s, (const unsigned*)g.d_ppm_len, n_chunks,
-                     (unsigned long long)hd.len, g.d_ppm_off);
-  if (n_chunks > 0) {
+    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s,
+                       (const unsigned char*)rgb_device, n_px, n_chunks, per_group, g.d_ppm_len, g.d_ppm_group);
     hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, (const unsigned long long*)g.d_ppm_off, hd,
-                       (unsigned char*)text_device);
+                       (const unsigned char*)rgb_device, n_px, (const unsigned*)g.d_ppm_len, (const unsigned*)g.d_ppm_group,
+                       per_group, hd, (unsigned char*)text_device, g.d_ppm_total_host);
   } else {
+    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream)); /* nobody else is writing the length word */
     HIP_TRY(hipMemcpyAsync(text_device, hd.text, (size_t)hd.len, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s)); /* hd lives on this stack frame */
+    *g.h_ppm_total = (unsigned long long)hd.len;
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(g.h_ppm_total, g.d_ppm_off + n_chunks, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  g.ppm_stream = s;
+  g.ppm_stream = s; /* the scan kernel has put the length into *h_ppm_total once the stream has drained */
   g.ppm_pending = true;
   if (bytes_out) return rt_hip_ppm_last_length(bytes_out);
   return RT_OK;
@@ -1174,7 +1179,7 @@ void rt_hip_shutdown(void) {
   if (g.d_rgb) (void)hipFree(g.d_rgb);
   if (g.d_canvas) (void)hipFree(g.d_canvas);
   if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
-  if (g.d_ppm_off) (void)hipFree(g.d_ppm_off);
+  if (g.d_ppm_group) (void)hipFree(g.d_ppm_group);
   if (g.d_ppm_text) (void)hipFree(g.d_ppm_text);
   if (g.h_ppm_total) (void)hipHostFree(g.h_ppm_total);
   if (g.ev0) (void)hipEventDestroy(g.ev0);
