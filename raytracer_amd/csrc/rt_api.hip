@@ -147,6 +147,9 @@ void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderA
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, (const DevSphere*)g.d_spheres,
                        (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list,
                        rgb, canvas, g.d_counters);
+  else if (BVH && stage == 4)
+    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 4 : 0, KIND>), grid, block, lds, s, g.d_scene,
+                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
   else if (BVH && stage == 3)
     hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 3 : 0, KIND>), grid, block, lds, s, g.d_scene,
                        (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
@@ -188,14 +191,19 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
     if (!bvh && g.scene.n_tris > 0 && g.scene.n_tris <= kMaxLdsTris) {
       stage = 1;
       lds = (size_t)g.scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
-    } else if (bvh && g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
-      stage = 2;
-      lds = (size_t)g.scene.n_bvh_nodes * sizeof(DevBvh2);
-      /* the traversal stacks too, while two workgroups still fit a CU's 160 KiB (the walk's register budget
-       * allows no more than two anyway) */
+    } else if (bvh) {
+      if (g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
+        stage = 2;
+        lds = (size_t)g.scene.n_bvh_nodes * sizeof(DevBvh2);
+      }
+      /* the traversal stacks too (for a large tree: the stacks alone), while two workgroups still fit a CU's
+       * 160 KiB (the walk's register budget allows no more than two anyway) */
       const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)g.scene.bvh_depth;
-      if (g.lds_stack && g.scene.bvh_depth >= 1 && lds + stacks <= kMaxLdsPerWorkgroup) {
-        stage = 3;
+      /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
+       * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %) */
+      const size_t room = stage == 2 ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3;
+      if (g.lds_stack && g.scene.bvh_depth >= 1 && lds + stacks <= room) {
+        stage = stage == 2 ? 3 : 4;
         lds += stacks;
       }
     }

@@ -27,7 +27,7 @@ def scenes():
     t0 = time.perf_counter()
     s = R.stock_scene("lighthouse", W, H)
     yield "lighthouse", s, time.perf_counter() - t0
-    for level in (6, 8):
+    for level in (6, 7, 8):
         t0 = time.perf_counter()
         s = mesh_scene(icosphere(level), W, H)
         yield f"icosphere{level}", s, time.perf_counter() - t0
