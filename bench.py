@@ -93,15 +93,17 @@ def side_measurements(hip, dev, steps=100):
     return out
 
 
-def pipelined_measurements(hip, dev, streams=3, steps=300):
+def pipelined_measurements(hip, dev, streams=4, steps=300):
     """Frames issued round-robin on several streams, each into an image of its own: the next frame's waves fill
     the CUs while the last waves of the previous one drain.  Reported beside the headline, which is timed on one
     stream so that a launch's duration and the frame time are the same thing."""
     out = {}
     ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
     bufs = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(streams)]
-    for name, scene, accel in (("cube_1080p", SCENE, R._ffi.RT_ACCEL_AUTO), ("lighthouse_1080p_bvh", "lighthouse", R._ffi.RT_ACCEL_BVH)):
-        hip.upload(R.stock_scene(scene, WIDTH, HEIGHT))
+    for name, scene, tr, accel in (("cube_1080p", SCENE, 0.0, R._ffi.RT_ACCEL_AUTO),
+                                   ("lighthouse_1080p_bvh", "lighthouse", 0.0, R._ffi.RT_ACCEL_BVH),
+                                   ("lighthouse_1080p_reflective_bvh", "lighthouse", 0.3, R._ffi.RT_ACCEL_BVH)):
+        hip.upload(R.stock_scene(scene, WIDTH, HEIGHT, tr))
         st = R._ffi.Stats()
         hip.render_device(bufs[0].data_ptr(), R.make_params(accel=accel, count_rays=True), stats=st)
         p = R.make_params(accel=accel)

@@ -7,8 +7,9 @@ import raytracer_amd as R
 
 r = R.HipRenderer(0)
 K = 400
-for scene, accel in (("cube", R._ffi.RT_ACCEL_AUTO), ("spheres", R._ffi.RT_ACCEL_AUTO), ("lighthouse", R._ffi.RT_ACCEL_BVH)):
-    r.upload(R.stock_scene(scene, 1920, 1080))
+for scene, accel in (("cube", R._ffi.RT_ACCEL_AUTO), ("spheres", R._ffi.RT_ACCEL_AUTO), ("lighthouse", R._ffi.RT_ACCEL_BVH),
+                     ("lighthouse_refl", R._ffi.RT_ACCEL_BVH)):
+    r.upload(R.stock_scene(scene.replace("_refl", ""), 1920, 1080, 0.3 if scene.endswith("_refl") else 0.0))
     p = R.make_params(accel=accel)
     for S in (1, 2, 3, 4, 8):
         streams = [torch.cuda.Stream() for _ in range(S)]
@@ -31,5 +32,5 @@ for scene, accel in (("cube", R._ffi.RT_ACCEL_AUTO), ("spheres", R._ffi.RT_ACCEL
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / K * 1e3)
         same = all(bool(torch.equal(b, bufs[0])) for b in bufs)
-        print(f"{scene:10s} streams {S}: {best:7.2f} us/frame  images identical={same}", flush=True)
+        print(f"{scene:16s} streams {S}: {best:7.2f} us/frame  images identical={same}", flush=True)
 r.shutdown()
