@@ -885,29 +885,48 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
     g.scene_serial++;
     return RT_OK;
   }
+  /* what the scene keeps afterwards: one allocation each; everything else: one allocation carved up */
   BuildBuffers b;
-  unsigned long long *keys, *keys_sorted;
-  unsigned *index, *index_sorted, *visits, *walked, *slot;
   DevTri* tris_out;
   DevTriPrimary* prim_out;
   double* normals_out;
-  float *leaf_lo, *leaf_hi, *node_lo, *node_hi;
-  int *left, *right, *range_lo, *range_hi, *parent_of_node, *parent_of_leaf, *node_depth;
   DevBvh2* nodes;
   const size_t nn = (size_t)n, ni = nn - 1;
-  if (!b.get(&keys, nn) || !b.get(&keys_sorted, nn) || !b.get(&index, nn) || !b.get(&index_sorted, nn) ||
-      !b.get(&visits, ni) || !b.get(&walked, ni) || !b.get(&slot, ni) || !b.get(&tris_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) ||
-      !b.get(&leaf_lo, 3 * nn) || !b.get(&leaf_hi, 3 * nn) || !b.get(&node_lo, 3 * ni) || !b.get(&node_hi, 3 * ni) ||
-      !b.get(&left, ni) || !b.get(&right, ni) || !b.get(&range_lo, ni) || !b.get(&range_hi, ni) ||
-      !b.get(&parent_of_node, ni) || !b.get(&parent_of_leaf, nn) || !b.get(&node_depth, ni) || !b.get(&nodes, ni))
-    return RT_ERR_HIP;
-  size_t sort_bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, index, index_sorted, n, 0, 63, g.stream));
-  size_t scan_bytes = 0;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, walked, slot, (int)ni, g.stream));
-  unsigned char* sort_space; /* both library calls work in it, one after the other */
-  const size_t space_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-  if (!b.get(&sort_space, space_bytes)) return RT_ERR_HIP;
+  if (!b.get(&tris_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
+  size_t sort_bytes = 0, scan_bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63, g.stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int)ni, g.stream));
+  const size_t space_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes; /* both library calls work in it, in turn */
+  size_t arena_bytes = 0;
+  auto reserve = [&](size_t bytes) { const size_t at = arena_bytes; arena_bytes += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t at_keys = reserve(8 * nn), at_keys_sorted = reserve(8 * nn), at_index = reserve(4 * nn), at_index_sorted = reserve(4 * nn);
+  const size_t at_visits = reserve(4 * ni), at_walked = reserve(4 * ni), at_slot = reserve(4 * ni);
+  const size_t at_leaf_lo = reserve(12 * nn), at_leaf_hi = reserve(12 * nn), at_node_lo = reserve(12 * ni), at_node_hi = reserve(12 * ni);
+  const size_t at_left = reserve(4 * ni), at_right = reserve(4 * ni), at_range_lo = reserve(4 * ni), at_range_hi = reserve(4 * ni);
+  const size_t at_parent_of_node = reserve(4 * ni), at_parent_of_leaf = reserve(4 * nn), at_node_depth = reserve(4 * ni);
+  const size_t at_space = reserve(space_bytes);
+  unsigned char* arena;
+  if (!b.get(&arena, arena_bytes)) return RT_ERR_HIP;
+  unsigned long long* keys = (unsigned long long*)(arena + at_keys);
+  unsigned long long* keys_sorted = (unsigned long long*)(arena + at_keys_sorted);
+  unsigned* index = (unsigned*)(arena + at_index);
+  unsigned* index_sorted = (unsigned*)(arena + at_index_sorted);
+  unsigned* visits = (unsigned*)(arena + at_visits);
+  unsigned* walked = (unsigned*)(arena + at_walked);
+  unsigned* slot = (unsigned*)(arena + at_slot);
+  float* leaf_lo = (float*)(arena + at_leaf_lo);
+  float* leaf_hi = (float*)(arena + at_leaf_hi);
+  float* node_lo = (float*)(arena + at_node_lo);
+  float* node_hi = (float*)(arena + at_node_hi);
+  int* left = (int*)(arena + at_left);
+  int* right = (int*)(arena + at_right);
+  int* range_lo = (int*)(arena + at_range_lo);
+  int* range_hi = (int*)(arena + at_range_hi);
+  int* parent_of_node = (int*)(arena + at_parent_of_node);
+  int* parent_of_leaf = (int*)(arena + at_parent_of_leaf);
+  int* node_depth = (int*)(arena + at_node_depth);
+  unsigned char* sort_space = arena + at_space;
 
   double scale[3];
   for (int c = 0; c < 3; ++c) {
