@@ -112,6 +112,29 @@ def test_large_mesh_without_a_tree_gets_one_at_upload(hip):
     assert np.array_equal(got, want)
 
 
+def test_camera_inside_a_large_mesh(hip):
+    """No pixel rectangle bounds the mesh when the camera sits inside it: every tile is a mesh tile, ordered in
+    per-XCD runs because the tree is read from memory."""
+    from raytracer_amd.scene import SceneBuilder
+
+    b = SceneBuilder()
+    b.set_camera(96, 64, 1.2, (0.1, 0.05, -0.2), (0.3, 0.2, 1.0))
+    b.set_light((0.2, 0.3, 0.1), (1, 1, 1))
+    b.add_triangles_f32(icosphere(5))
+    b.set_reflective(0.2, 0.0)
+    s = b.finish(4)
+    assert s.n_bvh_nodes > 2 * 768
+    hip.upload(s)
+    got, st = hip.render(accel=BVH, count_rays=True)
+    brute, sb = hip.render(accel=BRUTE, count_rays=True)
+    assert np.array_equal(got, brute) and st.rays == sb.rays and st.rays_shadow == 96 * 64 + st.rays_secondary
+    want, ost = O.render_rgb(s)
+    assert np.array_equal(got, want) and st.rays == ost.rays
+    hip.build_bvh_device(4)
+    dev, sd = hip.render(accel=BVH, count_rays=True)
+    assert np.array_equal(dev, want) and sd.rays == ost.rays
+
+
 def test_large_meshes_device_tree(hip):
     """81,920 triangles against the oracle, 1.3 million against the host tree; build times are printed."""
     s = mesh_scene(icosphere(6), 64, 48, reflective=0.25)
