@@ -12,13 +12,18 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define NBINS 16
 
 typedef struct { double lo[3], hi[3]; } box_t;
 typedef struct { box_t b; double c[3]; int tri; } prim_t;
+
+/* a subtree left for a worker thread: the node that stands for it in the top of the tree, and its triangles */
+typedef struct { int node, first, count; } task_t;
 
 typedef struct {
   prim_t* prims;
@@ -26,6 +31,10 @@ typedef struct {
   int n_nodes, cap_nodes;
   int leaf_size;
   double pad;
+  /* top of a parallel build only: ranges of at most defer_count triangles become tasks instead of subtrees */
+  int defer_count;
+  task_t* tasks;
+  int n_tasks, cap_tasks;
 } build_t;
 
 static void box_empty(box_t* b) {
@@ -58,6 +67,21 @@ static int new_node(build_t* B) {
 static int build_range(build_t* B, int first, int count) {
   int me = new_node(B);
   if (me < 0) return -1;
+  if (B->defer_count > 0 && count <= B->defer_count && count > B->leaf_size) {
+    if (B->n_tasks == B->cap_tasks) {
+      int nc = B->cap_tasks ? B->cap_tasks * 2 : 64;
+      task_t* q = realloc(B->tasks, sizeof(task_t) * (size_t)nc);
+      if (!q) return -1;
+      B->tasks = q; B->cap_tasks = nc;
+    }
+    B->tasks[B->n_tasks].node = me;
+    B->tasks[B->n_tasks].first = first;
+    B->tasks[B->n_tasks].count = count;
+    B->n_tasks++;
+    B->nodes[me].left = first; /* a leaf for now; the subtree's root replaces it */
+    B->nodes[me].right = -1;
+    return me;
+  }
   box_t nb, cb;
   box_empty(&nb); box_empty(&cb);
   for (int i = first; i < first + count; ++i) {
@@ -163,6 +187,85 @@ static int build_range(build_t* B, int first, int count) {
   return me;
 }
 
+/* ---- subtrees on worker threads ----
+ * The ranges of different tasks are disjoint parts of `prims`, every worker has a node array of its own, and
+ * tasks are handed out by a counter under a mutex; the subtrees are spliced into the top afterwards, in task
+ * order, so the tree does not depend on the number of threads or on their timing. */
+typedef struct {
+  const build_t* top;
+  build_t* sub;           /* one per task */
+  int* status;            /* build_range's result per task */
+  int next;
+  pthread_mutex_t lock;
+} pool_t;
+
+static void* pool_worker(void* arg) {
+  pool_t* P = arg;
+  for (;;) {
+    pthread_mutex_lock(&P->lock);
+    const int t = P->next < P->top->n_tasks ? P->next++ : -1;
+    pthread_mutex_unlock(&P->lock);
+    if (t < 0) return NULL;
+    build_t* S = &P->sub[t];
+    memset(S, 0, sizeof *S);
+    S->prims = P->top->prims;
+    S->leaf_size = P->top->leaf_size;
+    S->pad = P->top->pad;
+    P->status[t] = build_range(S, P->top->tasks[t].first, P->top->tasks[t].count);
+  }
+}
+
+static int host_threads(void) {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  const char* e = getenv("RT_HOST_THREADS");
+  if (e && atoi(e) > 0) n = atoi(e);
+  if (n < 1) n = 1;
+  if (n > 16) n = 16;
+  return (int)n;
+}
+
+/* build the deferred subtrees and put them behind the top nodes: node j > 0 of task t becomes node
+ * base_t + j - 1, its root replaces the placeholder (children keep following their parent in the array) */
+static int build_tasks(build_t* B, int n_threads) {
+  pool_t P;
+  memset(&P, 0, sizeof P);
+  P.top = B;
+  P.sub = calloc((size_t)B->n_tasks, sizeof(build_t));
+  P.status = calloc((size_t)B->n_tasks, sizeof(int));
+  pthread_t* th = calloc((size_t)n_threads, sizeof(pthread_t));
+  int ok = P.sub && P.status && th && pthread_mutex_init(&P.lock, NULL) == 0;
+  int started = 0;
+  if (ok) {
+    for (int i = 0; i < n_threads - 1; ++i)
+      if (pthread_create(&th[started], NULL, pool_worker, &P) == 0) started++;
+    pool_worker(&P); /* this thread works too: the build completes even if no thread could be started */
+    for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+    pthread_mutex_destroy(&P.lock);
+    for (int t = 0; t < B->n_tasks && ok; ++t) ok = P.status[t] == 0;
+  }
+  size_t extra = 0;
+  for (int t = 0; t < B->n_tasks && ok; ++t) extra += (size_t)P.sub[t].n_nodes - 1;
+  if (ok && extra > 0) {
+    if ((size_t)B->n_nodes + extra > (size_t)0x7fffffff) ok = 0;
+    rt_bvh_node* q = ok ? realloc(B->nodes, sizeof(rt_bvh_node) * ((size_t)B->n_nodes + extra)) : NULL;
+    if (!q) ok = 0;
+    else { B->nodes = q; B->cap_nodes = B->n_nodes + (int)extra; }
+  }
+  for (int t = 0; t < B->n_tasks && ok; ++t) {
+    const build_t* S = &P.sub[t];
+    const int base = B->n_nodes;
+    for (int j = 0; j < S->n_nodes; ++j) {
+      rt_bvh_node nd = S->nodes[j];
+      if (nd.right >= 0) { nd.left += base - 1; nd.right += base - 1; } /* inner: children are nodes >= 1 of the subtree */
+      B->nodes[j == 0 ? B->tasks[t].node : base + j - 1] = nd;
+    }
+    B->n_nodes += S->n_nodes - 1;
+  }
+  if (P.sub) for (int t = 0; t < B->n_tasks; ++t) free(P.sub[t].nodes);
+  free(P.sub); free(P.status); free(th);
+  return ok ? 0 : -1;
+}
+
 int rt_bvh_build(const double* p123, int n, int leaf_size, rt_bvh_node** nodes, int* n_nodes, int32_t** tri_index) {
   if (!p123 || n < 1 || leaf_size < 1 || !nodes || !n_nodes || !tri_index) return RT_ERR_INVALID;
   build_t B;
@@ -186,7 +289,14 @@ int rt_bvh_build(const double* p123, int n, int leaf_size, rt_bvh_node** nodes, 
     p->tri = i;
   }
   B.pad = 1e-6 * amax;
-  if (build_range(&B, 0, n) < 0) { free(B.prims); free(B.nodes); return RT_ERR_INVALID; }
+  const int n_threads = host_threads();
+  /* two or more subtrees per thread: finer tasks balance better but lengthen the single-threaded top of the build */
+  if (n_threads > 1 && n >= 65536) B.defer_count = n / (2 * n_threads);
+  int rc = build_range(&B, 0, n) < 0 ? -1 : 0;
+  B.defer_count = 0;
+  if (rc == 0 && B.n_tasks > 0) rc = build_tasks(&B, n_threads);
+  free(B.tasks);
+  if (rc < 0) { free(B.prims); free(B.nodes); return RT_ERR_INVALID; }
   int32_t* idx = malloc(sizeof(int32_t) * (size_t)n);
   if (!idx) { free(B.prims); free(B.nodes); return RT_ERR_INVALID; }
   for (int i = 0; i < n; ++i) idx[i] = B.prims[i].tri;

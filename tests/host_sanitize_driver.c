@@ -31,5 +31,19 @@ int main(void) {
       rt_scene_destroy(b);
     }
   }
+  { /* 70000 triangles: the BVH builder hands subtrees to worker threads */
+    rt_scene_builder* b = rt_scene_create();
+    if (rt_scene_stock(b, "lighthouse", 64, 48) != RT_OK) return 1;
+    const int n = 70000;
+    float* v = malloc(sizeof(float) * 9 * (size_t)n);
+    for (int i = 0; i < 9 * n; ++i) v[i] = (float)rand() / RAND_MAX * 4.f - 2.f;
+    int rc = rt_scene_add_triangles_f32(b, v, n, NULL);
+    free(v);
+    rt_scene s;
+    if (rc == RT_OK) rc = rt_scene_finish(b, 4, &s);
+    printf("threaded build: rc %d tris %d nodes %d\n", rc, s.n_tris, s.n_bvh_nodes);
+    rt_scene_destroy(b);
+    if (rc != RT_OK) return 1;
+  }
   return 0;
 }

@@ -172,3 +172,37 @@ def test_plain_worlds_do_not_carry_the_material_extension():
         s = R.stock_scene(name, 32, 24, tr, sr)
         assert not s.materials_ext and s.n_shapes == 0
     assert R.stock_scene("refraction", 32, 24).materials_ext
+
+
+def test_threaded_bvh_build_equals_the_single_threaded_one(monkeypatch):
+    """From 65,536 triangles up the host builder hands subtrees to worker threads; the tree (walked from the root)
+    and the triangle order must not depend on the number of threads."""
+    import ctypes as C
+
+    from raytracer_amd.scene import SceneBuilder
+    from test_hip_parity import icosphere
+
+    def build(threads):
+        monkeypatch.setenv("RT_HOST_THREADS", str(threads))
+        b = SceneBuilder()
+        b.set_camera(64, 48, 0.7, (0.3, 1.2, -4.0), (0, 0, 0))
+        b.set_light((-4.0, 6.0, -5.0), (1, 1, 1))
+        b.add_triangles_f32(icosphere(6))
+        s = b.finish(4)
+        words = np.ctypeslib.as_array(C.cast(s.bvh_nodes, C.POINTER(C.c_int32)), shape=(s.n_bvh_nodes, 8)).copy()
+        order = np.ctypeslib.as_array(s.bvh_tri, shape=(s.n_tris,)).copy()
+        walk, stack = [], [0]
+        while stack:
+            i = stack.pop()
+            left, right = int(words[i][3]), int(words[i][7])  # lo[3] left hi[3] right
+            walk.append(tuple(words[i][[0, 1, 2, 4, 5, 6]]) + ((left, right) if right < 0 else (-1, 0)))
+            if right >= 0:
+                assert left > i and right > i  # children follow their parent in the array
+                stack += [right, left]
+        assert len(walk) == s.n_bvh_nodes  # no node is left unreachable by the splice
+        return walk, order
+
+    one, order_one = build(1)
+    for threads in (3, 8):
+        many, order_many = build(threads)
+        assert many == one and np.array_equal(order_many, order_one)
