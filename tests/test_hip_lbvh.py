@@ -135,6 +135,26 @@ def test_camera_inside_a_large_mesh(hip):
     assert np.array_equal(dev, want) and sd.rays == ost.rays
 
 
+def test_spheres_beside_a_large_mesh(hip):
+    """Spheres stay outside the tree; with a tree that is read from memory the tiles are still ordered per XCD."""
+    from raytracer_amd.scene import SceneBuilder
+
+    b = SceneBuilder()
+    b.set_camera(64, 40, 0.8, (0.3, 1.2, -4.5), (0, 0, 0))
+    b.set_light((-4.0, 6.0, -5.0), (1, 1, 1))
+    b.add_sphere(R.Mat4.mul(R.Mat4.translate(1.6, 0.2, -0.5), R.Mat4.scale(0.5, 0.5, 0.5)), R.default_material(reflective=0.4))
+    b.add_triangles_f32(icosphere(5))
+    b.add_sphere(R.Mat4.mul(R.Mat4.translate(-1.5, -0.3, -0.8), R.Mat4.scale(0.4, 0.7, 0.4)), R.default_material())
+    b.set_reflective(0.2, 0.4)
+    for leaf in (4, 0):  # host tree, then the tree built at upload
+        s = b.finish(leaf)
+        hip.upload(s)
+        got, st = hip.render(count_rays=True)
+        assert st.accel_used == BVH
+        want, ost = O.render_rgb(s)
+        assert np.array_equal(got, want) and st.rays == ost.rays
+
+
 def test_large_meshes_device_tree(hip):
     """81,920 triangles against the oracle, 1.3 million against the host tree; build times are printed."""
     s = mesh_scene(icosphere(6), 64, 48, reflective=0.25)
