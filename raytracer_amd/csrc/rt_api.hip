@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "rt_kernels.hip.inc"
@@ -32,6 +33,7 @@ struct Context {
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
   bool lds_stack = true;
+  bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
@@ -48,6 +50,7 @@ struct Context {
   DevScene* d_scene = nullptr; /* device copy of `scene` */
   double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
   double box_pad = 0.0; /* what every single-precision box is grown by */
+  std::vector<float> tri_rect; /* pixel rectangle (x0 y0 x1 y1) of every triangle as the camera sees it; empty: unknown */
   /* tile order of the last plan and the parameters it was made for */
   int32_t* d_tile_list = nullptr;
   size_t tile_list_cap = 0;
@@ -137,6 +140,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
+constexpr int kMaxTilePlanTris = 1 << 18;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
@@ -311,6 +315,36 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
         if (src < nh) by_xcd.push_back(heavy[src]);
       }
       heavy.swap(by_xcd);
+    }
+    if (!by_xcd_wanted && g.crowded_first && !g.tri_rect.empty() && heavy.size() > 1) {
+      /* Longest first: the tiles that many triangles project into hold the waves that run longest, and a frame
+       * ends when its last wave does.  Count, per 16 x 16 cell of the image, the triangles whose pixel rectangle
+       * touches it, and start the mesh tiles in descending order of that count (ties stay in raster order). */
+      const int cells_y = (g.scene.vsize + RT_TILE_H - 1) / RT_TILE_H;
+      std::vector<int> crowd((size_t)tiles_x * cells_y, 0);
+      const size_t n_rect = g.tri_rect.size() / 4;
+      for (size_t k = 0; k < n_rect; ++k) {
+        const float* q = &g.tri_rect[4 * k];
+        if (!(q[2] >= 0.f && q[3] >= 0.f && q[0] < (float)W && q[1] < (float)g.scene.vsize)) continue;
+        const int cx0 = std::max(0, (int)(q[0] / RT_TILE_W)), cx1 = std::min(tiles_x - 1, (int)(q[2] / RT_TILE_W));
+        const int cy0 = std::max(0, (int)(q[1] / RT_TILE_H)), cy1 = std::min(cells_y - 1, (int)(q[3] / RT_TILE_H));
+        if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) continue; /* a triangle across the whole image says nothing */
+        for (int cy = cy0; cy <= cy1; ++cy)
+          for (int cx = cx0; cx <= cx1; ++cx) crowd[(size_t)cy * tiles_x + cx]++;
+      }
+      std::vector<int> cost(heavy.size());
+      std::vector<int32_t> order(heavy.size());
+      for (size_t i = 0; i < heavy.size(); ++i) {
+        const int tx = heavy[i] % tiles_x, ty = heavy[i] / tiles_x;
+        const int y = rt_hip_rank_row_to_y(ty * RT_TILE_H, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank);
+        const int cy = std::min(cells_y - 1, std::max(0, y / RT_TILE_H));
+        cost[i] = crowd[(size_t)cy * tiles_x + tx];
+        order[i] = (int32_t)i;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) { return cost[a_] > cost[b_]; });
+      std::vector<int32_t> sorted(heavy.size());
+      for (size_t i = 0; i < heavy.size(); ++i) sorted[i] = heavy[order[i]];
+      heavy.swap(sorted);
     }
     g.plan_heavy = (int)heavy.size();
     g.plan_tiles = n_tiles;
@@ -661,6 +695,7 @@ int rt_hip_init(int device) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("RT_HIP_CROWDED_FIRST")) g.crowded_first = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_XCD_TILES")) g.xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) g.lds_stack = atoi(e) != 0; /* tuning knob: 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS")) g.use_lds = atoi(e) != 0; /* tuning knob: 0 = read primitives from global memory */
@@ -856,6 +891,30 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     d.box_hi[c] = nt ? std::nextafterf((float)(bhi[c] + pad), INFINITY) : 0.f;
   }
   for (int c = 0; c < 3; ++c) { g.mesh_lo[c] = blo[c] - pad; g.mesh_hi[c] = bhi[c] + pad; }
+  /* where each triangle lands on the image: the tile order of a launch puts crowded tiles first */
+  g.tri_rect.clear();
+  double view[16];
+  if (nt > 0 && nt <= kMaxTilePlanTris && invert4(sc->camera.inv_view, view)) {
+    g.tri_rect.resize(4 * (size_t)nt);
+    const double W = sc->camera.hsize, H = sc->camera.vsize;
+    for (int k = 0; k < nt; ++k) {
+      const DevTri& t = ht[k];
+      float x0 = 1e30f, y0 = 1e30f, x1 = -1e30f, y1 = -1e30f;
+      for (int v = 0; v < 3; ++v) {
+        double w[3];
+        for (int c = 0; c < 3; ++c) w[c] = t.p1[c] + (v == 1 ? t.e1[c] : (v == 2 ? t.e2[c] : 0.0));
+        double c3[3];
+        for (int r = 0; r < 3; ++r) c3[r] = view[4 * r] * w[0] + view[4 * r + 1] * w[1] + view[4 * r + 2] * w[2] + view[4 * r + 3];
+        if (!(c3[2] < -1e-6)) { x0 = 0.f; y0 = 0.f; x1 = (float)W; y1 = (float)H; break; } /* beside or behind the camera */
+        const double px = (sc->camera.half_width - c3[0] / -c3[2]) / sc->camera.pixel_size;
+        const double py = (sc->camera.half_height - c3[1] / -c3[2]) / sc->camera.pixel_size;
+        x0 = std::fmin(x0, (float)px); x1 = std::fmax(x1, (float)px);
+        y0 = std::fmin(y0, (float)py); y1 = std::fmax(y1, (float)py);
+      }
+      float* q = &g.tri_rect[4 * (size_t)k];
+      q[0] = x0 - 1.f; q[1] = y0 - 1.f; q[2] = x1 + 1.f; q[3] = y1 + 1.f;
+    }
+  }
   g.box_pad = pad;
   g.scene_serial++;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
