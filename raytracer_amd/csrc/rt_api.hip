@@ -341,7 +341,16 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
         cost[i] = crowd[(size_t)cy * tiles_x + tx];
         order[i] = (int32_t)i;
       }
-      std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) { return cost[a_] > cost[b_]; });
+      /* equally crowded tiles: nearer the middle of the mesh's pixel rectangle first (more of their pixels are
+       * covered) */
+      const double ccx = 0.5 * (x0 + x1), ccy = 0.5 * (y0 + y1);
+      auto dist2 = [&](int32_t i) {
+        const double dx = (heavy[i] % tiles_x + 0.5) * RT_TILE_W - ccx, dy = (heavy[i] / tiles_x + 0.5) * RT_TILE_H - ccy;
+        return dx * dx + dy * dy;
+      };
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) {
+        if (cost[a_] != cost[b_]) return cost[a_] > cost[b_];
+        return have_rect ? dist2(a_) < dist2(b_) : false; });
       std::vector<int32_t> sorted(heavy.size());
       for (size_t i = 0; i < heavy.size(); ++i) sorted[i] = heavy[order[i]];
       heavy.swap(sorted);
