@@ -565,23 +565,89 @@ int upload_general(const rt_scene* sc, bool only_form) {
 }
 
 template <bool COUNT, bool F64OUT>
-void launch_general_cap(dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+void launch_general_cap(dim3 grid, hipStream_t s, const RenderArgs& a, const int32_t* tile_list, int32_t* probe_cost,
+                        unsigned char* rgb, double* canvas) {
   const dim3 block(RT_TILE_W * RT_TILE_H);
   if (g.gen_list_cap <= 32)
     hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 32>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
-                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, rgb, canvas, g.d_counters);
+                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, tile_list, probe_cost, rgb,
+                       canvas, g.d_counters);
   else
     hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 100>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
-                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, rgb, canvas, g.d_counters);
+                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, tile_list, probe_cost, rgb,
+                       canvas, g.d_counters);
 }
 void launch_general(bool count, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
   if (count) {
-    if (f64) launch_general_cap<true, true>(grid, s, a, rgb, canvas);
-    else launch_general_cap<true, false>(grid, s, a, rgb, canvas);
+    if (f64) launch_general_cap<true, true>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
+    else launch_general_cap<true, false>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
   } else {
-    if (f64) launch_general_cap<false, true>(grid, s, a, rgb, canvas);
-    else launch_general_cap<false, false>(grid, s, a, rgb, canvas);
+    if (f64) launch_general_cap<false, true>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
+    else launch_general_cap<false, false>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
   }
+}
+
+/* Tile order for launches of the general kernel.  What a tile costs there is the size of its pixels' ray trees
+ * (mirrors and glass, also on planes that no pixel rectangle bounds), so it is measured: one small launch traces
+ * four pixels of every tile and counts their rays, and the tiles then start, block by block, in descending order
+ * of that count.
+ * Kept, like plan_tiles' list and in the same buffer, until the scene, the band layout or the depth changes. */
+int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const RenderArgs& a) {
+  g.launch_tile_list = nullptr;
+  if (!g.tile_plan) return RT_OK;
+  const int tiles_x = (g.scene.hsize + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+  const long long n_tiles_ll = (long long)tiles_x * tiles_y;
+  if (n_tiles_ll < 64 || n_tiles_ll > (1 << 28)) return RT_OK; /* a launch this small has no tail worth ordering */
+  const int n_tiles = (int)n_tiles_ll;
+  const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
+                            -2 - (long long)p->max_depth - ((long long)(p->accel == RT_ACCEL_REFERENCE) << 20)};
+  if (memcmp(key, g.plan_key, sizeof key) != 0) {
+    HIP_TRY(hipDeviceSynchronize()); /* launches in flight on other streams read the list that is about to change */
+    int32_t* d_cost = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cost, sizeof(int32_t) * (size_t)n_tiles));
+    std::vector<int32_t> cost((size_t)n_tiles), order((size_t)n_tiles);
+    RenderArgs pa = a;
+    pa.ablate = RT_GEN_PROBE;
+    pa.spp_grid = 1;
+    pa.sample_off[0] = 0.5;
+    hipError_t e = hipMemsetAsync(d_cost, 0, sizeof(int32_t) * (size_t)n_tiles, s);
+    if (e == hipSuccess) {
+      const unsigned threads = RT_TILE_W * RT_TILE_H;
+      launch_general_cap<true, false>(dim3((unsigned)(((size_t)n_tiles * 4 + threads - 1) / threads)), s, pa, nullptr, d_cost,
+                                      nullptr, nullptr);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cost.data(), d_cost, sizeof(int32_t) * (size_t)n_tiles, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_cost);
+    if (!hip_ok(e, "tile cost probe")) return RT_ERR_HIP;
+    for (int t = 0; t < n_tiles; ++t) order[t] = t;
+    /* whole blocks of 8 x 8 tiles, by the summed estimate, tiles in raster order inside a block: measured better
+     * than tile by tile (refraction frame 0.418 ms unordered, 0.394 tile by tile, 0.375 in blocks) */
+    const int blk = 8;
+    const int bx = (tiles_x + blk - 1) / blk, by = (tiles_y + blk - 1) / blk;
+    std::vector<long long> block_cost((size_t)bx * by, 0);
+    auto block_of = [&](int32_t t) { return (size_t)((t / tiles_x) / blk) * bx + (size_t)((t % tiles_x) / blk); };
+    for (int t = 0; t < n_tiles; ++t) block_cost[block_of(t)] += cost[t];
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) {
+      const size_t ba = block_of(a_), bb = block_of(b_);
+      if (ba == bb) return false;
+      if (block_cost[ba] != block_cost[bb]) return block_cost[ba] > block_cost[bb];
+      return ba < bb;
+    });
+    if ((size_t)n_tiles > g.tile_list_cap) {
+      if (g.d_tile_list) (void)hipFree(g.d_tile_list);
+      g.d_tile_list = nullptr;
+      g.tile_list_cap = 0;
+      HIP_TRY(hipMalloc((void**)&g.d_tile_list, sizeof(int32_t) * (size_t)n_tiles));
+      g.tile_list_cap = (size_t)n_tiles;
+    }
+    HIP_TRY(hipMemcpyAsync(g.d_tile_list, order.data(), sizeof(int32_t) * (size_t)n_tiles, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
+    memcpy(g.plan_key, key, sizeof key);
+  }
+  g.launch_tile_list = g.d_tile_list;
+  return RT_OK;
 }
 
 int check_params(const rt_render_params* p) {
@@ -627,8 +693,12 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
     if (general) {
       a.n_heavy = (int)n_tiles;
       a.light_per_block = 1;
+      a.ablate = 0; /* the timing cuts are the fast kernels'; this kernel reads the field as "probe launch" */
+      a.pad = 0;
       n_blocks = (int)n_tiles;
       bvh = false;
+      const int prc = plan_general_tiles(p, rows, s, a);
+      if (prc != RT_OK) return prc;
     } else {
       const int prc = plan_tiles(p, rows, s, a, n_blocks);
       if (prc != RT_OK) return prc;
