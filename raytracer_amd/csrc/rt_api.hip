@@ -205,8 +205,9 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
        * 160 KiB (the walk's register budget allows no more than two anyway) */
       const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)g.scene.bvh_depth;
       /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
-       * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %) */
-      const size_t room = stage == 2 ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3;
+       * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
+       * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
+      const size_t room = stage == 2 || reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3;
       if (g.lds_stack && g.scene.bvh_depth >= 1 && lds + stacks <= room) {
         stage = stage == 2 ? 3 : 4;
         lds += stacks;

@@ -29,7 +29,7 @@ def scenes():
     yield "lighthouse", s, time.perf_counter() - t0
     for level in (6, 7, 8):
         t0 = time.perf_counter()
-        s = mesh_scene(icosphere(level), W, H)
+        s = mesh_scene(icosphere(level), W, H, reflective=float(os.environ.get("LBVH_REFL", "0")))
         yield f"icosphere{level}", s, time.perf_counter() - t0
 
 
