@@ -140,7 +140,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
-constexpr int kMaxTilePlanTris = 1 << 18;  /* meshes up to this size get their tiles ordered by how crowded they are */
+constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
@@ -304,23 +304,11 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
         (hit ? heavy : light).push_back(ty * tiles_x + tx);
       }
     }
-    if (by_xcd_wanted && heavy.size() >= 64) {
-      /* Workgroups b and b + 8 run on the same XCD and share its L2: give each XCD one contiguous run of the
-       * mesh tiles instead of every eighth, so that what its L2 holds of the tree is what its tiles walk
-       * (81,920 triangles -10 %, 327,680 -18 %, 1.31 M -9 %; a tree that sits in LDS gains nothing, +5 %). */
-      const size_t nh = heavy.size(), per = (nh + 7) / 8;
-      std::vector<int32_t> by_xcd;
-      by_xcd.reserve(nh);
-      for (size_t b = 0; b < per * 8; ++b) {
-        const size_t src = (b % 8) * per + b / 8;
-        if (src < nh) by_xcd.push_back(heavy[src]);
-      }
-      heavy.swap(by_xcd);
-    }
-    if (!by_xcd_wanted && g.crowded_first && !g.tri_rect.empty() && heavy.size() > 1) {
-      /* Longest first: the tiles that many triangles project into hold the waves that run longest, and a frame
-       * ends when its last wave does.  Count, per 16 x 16 cell of the image, the triangles whose pixel rectangle
-       * touches it, and start the mesh tiles in descending order of that count (ties stay in raster order). */
+    /* Longest first: the tiles that many triangles project into hold the waves that run longest, and a frame
+     * ends when its last wave does.  Count, per 16 x 16 cell of the image, the triangles whose pixel rectangle
+     * touches it; the mesh tiles start in descending order of that count. */
+    std::vector<int> cost;
+    if (g.crowded_first && !g.tri_rect.empty() && heavy.size() > 1) {
       const int cells_y = (g.scene.vsize + RT_TILE_H - 1) / RT_TILE_H;
       std::vector<int> crowd((size_t)tiles_x * cells_y, 0);
       const size_t n_rect = g.tri_rect.size() / 4;
@@ -333,27 +321,48 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
         for (int cy = cy0; cy <= cy1; ++cy)
           for (int cx = cx0; cx <= cx1; ++cx) crowd[(size_t)cy * tiles_x + cx]++;
       }
-      std::vector<int> cost(heavy.size());
-      std::vector<int32_t> order(heavy.size());
+      cost.resize(heavy.size());
       for (size_t i = 0; i < heavy.size(); ++i) {
         const int tx = heavy[i] % tiles_x, ty = heavy[i] / tiles_x;
         const int y = rt_hip_rank_row_to_y(ty * RT_TILE_H, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank);
         const int cy = std::min(cells_y - 1, std::max(0, y / RT_TILE_H));
         cost[i] = crowd[(size_t)cy * tiles_x + tx];
-        order[i] = (int32_t)i;
       }
-      /* equally crowded tiles: nearer the middle of the mesh's pixel rectangle first (more of their pixels are
-       * covered) */
-      const double ccx = 0.5 * (x0 + x1), ccy = 0.5 * (y0 + y1);
-      auto dist2 = [&](int32_t i) {
-        const double dx = (heavy[i] % tiles_x + 0.5) * RT_TILE_W - ccx, dy = (heavy[i] / tiles_x + 0.5) * RT_TILE_H - ccy;
-        return dx * dx + dy * dy;
-      };
-      std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) {
-        if (cost[a_] != cost[b_]) return cost[a_] > cost[b_];
-        return have_rect ? dist2(a_) < dist2(b_) : false; });
-      std::vector<int32_t> sorted(heavy.size());
-      for (size_t i = 0; i < heavy.size(); ++i) sorted[i] = heavy[order[i]];
+    }
+    /* positions [from, to) of `heavy` (still in raster order) by descending cost; equally crowded tiles: nearer
+     * the middle of the mesh's pixel rectangle first (more of their pixels are covered) */
+    const double ccx = 0.5 * (x0 + x1), ccy = 0.5 * (y0 + y1);
+    auto by_cost = [&](size_t from, size_t to) {
+      std::vector<int32_t> order(to - from);
+      for (size_t i = from; i < to; ++i) order[i - from] = (int32_t)i;
+      if (!cost.empty()) {
+        auto dist2 = [&](int32_t i) {
+          const double dx = (heavy[i] % tiles_x + 0.5) * RT_TILE_W - ccx, dy = (heavy[i] / tiles_x + 0.5) * RT_TILE_H - ccy;
+          return dx * dx + dy * dy;
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a_, int32_t b_) {
+          if (cost[a_] != cost[b_]) return cost[a_] > cost[b_];
+          return have_rect ? dist2(a_) < dist2(b_) : false;
+        });
+      }
+      for (int32_t& i : order) i = heavy[i];
+      return order;
+    };
+    if (by_xcd_wanted && heavy.size() >= 64) {
+      /* Workgroups b and b + 8 run on the same XCD and share its L2: give each XCD one contiguous run of the
+       * mesh tiles instead of every eighth, so that what its L2 holds of the tree is what its tiles walk
+       * (81,920 triangles -10 %, 327,680 -18 %, 1.31 M -9 %; a tree that sits in LDS gains nothing, +5 %).
+       * Inside its run every XCD starts with the most crowded tiles. */
+      const size_t nh = heavy.size(), per = (nh + 7) / 8;
+      std::vector<int32_t> run[8];
+      for (size_t x = 0; x < 8; ++x) run[x] = by_cost(std::min(nh, x * per), std::min(nh, (x + 1) * per));
+      std::vector<int32_t> by_xcd;
+      by_xcd.reserve(nh);
+      for (size_t b = 0; b < per * 8; ++b)
+        if (b / 8 < run[b % 8].size()) by_xcd.push_back(run[b % 8][b / 8]);
+      heavy.swap(by_xcd);
+    } else if (!cost.empty()) {
+      std::vector<int32_t> sorted = by_cost(0, heavy.size());
       heavy.swap(sorted);
     }
     g.plan_heavy = (int)heavy.size();
