@@ -285,7 +285,7 @@ int plan_tiles(const rt_render_params* p, int rows, hipStream_t s, RenderArgs& a
   const bool by_xcd_wanted = g.xcd_tiles == 1 || (g.xcd_tiles < 0 && tree_in_memory);
   const bool have_rect = g.scene.n_spheres == 0 && mesh_pixel_rect(g.host_camera, x0, y0, x1, y1);
   /* no rectangle (the camera is inside the bounds, say): every tile counts as a mesh tile */
-  if (!have_rect && !by_xcd_wanted) return RT_OK;
+  if (!have_rect && !by_xcd_wanted && (g.tri_rect.empty() || !g.crowded_first)) return RT_OK;
   const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
                             g.light_per_block};
   if (memcmp(key, g.plan_key, sizeof key) != 0) {
