@@ -39,3 +39,47 @@ def test_more_ranks_than_rows_and_tiny_supersampled_images(hip, scene):
         out[ys] = part
         rows += len(ys)
     assert rows == 5 and np.array_equal(out, full)
+
+
+def _box_triangles(lo, hi):
+    """The 12 triangles of an axis-aligned box."""
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    v = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+    quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+    tris = []
+    for a, b, c, d in quads:
+        tris += [v[a] + v[b] + v[c], v[a] + v[c] + v[d]]
+    return np.array(tris, dtype=np.float32)
+
+
+@pytest.mark.parametrize("eye,to", [((0.0, 0.0, -6.0), (0.0, 0.0, 0.0)), ((0.0, 5.0, 0.0), (0.0, 0.0, 0.0)),
+                                    ((-7.0, 0.5, 0.0), (0.0, 0.5, 0.0))])
+def test_rays_parallel_to_the_axes_through_the_bvh(hip, eye, to):
+    """A camera on an axis looking along it at axis-aligned boxes, odd image size: the middle column and row have
+    direction components of exactly zero, mirror bounces keep them, and coordinates of exactly zero abound.  The
+    walk's single-precision slab test (fused lo/d - o/d with a clamped reciprocal) must not lose a box."""
+    from raytracer_amd.scene import SceneBuilder
+
+    b = SceneBuilder()
+    up = (0.0, 0.0, 1.0) if eye[1] != 0.0 and eye[0] == 0.0 and eye[2] == 0.0 else (0.0, 1.0, 0.0)
+    b.set_camera(33, 33, 0.9, eye, to, up)
+    b.set_light((-4.0, 6.0, -5.0), (1, 1, 1))
+    tris = np.concatenate([_box_triangles((-1, -1, -1), (1, 1, 1)), _box_triangles((0.125, 0.0625, 1.25), (2, 2, 3)),
+                           _box_triangles((-3, -2, -0.5), (-1.5, 0.375, 0.5)), _box_triangles((-0.25, -3, -0.25), (0.25, 3, 0.25))])
+    b.add_triangles_f32(tris)
+    b.set_reflective(0.5, 0.0)
+    s = b.finish(1)  # one triangle per leaf: every hit goes through several levels of boxes
+    assert s.n_bvh_nodes > 48
+    hip.upload(s)
+    tree, st = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    brute, sb = hip.render(accel=R._ffi.RT_ACCEL_BRUTE, count_rays=True)
+    want, ost = O.render_rgb(s)
+    # no ray origin exactly in the plane of a triangle it is tested against: the list quirk of RayTracer.c:168
+    # (an entry with t == 0.0 is overwritten by the next one) is outside what the mesh kernels reproduce
+    assert O.probe().exact_zero_t == 0 and O.probe().list_overflow == 0
+    assert np.array_equal(tree, brute) and np.array_equal(tree, want)
+    assert st.rays == sb.rays == ost.rays and st.rays_secondary > 0
+    hip.build_bvh_device(1)
+    dev, sd = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    assert np.array_equal(dev, want) and sd.rays == ost.rays
