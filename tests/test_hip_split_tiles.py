@@ -1,0 +1,26 @@
+"""Crowded mesh tiles run as two or four workgroups with a half or a quarter of each wave's lanes: whatever the
+split, every pixel is traced exactly once and the image equals the exhaustive loop's and the oracle's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("parts,tiles,min_cost", [(2, 100000, 1), (4, 100000, 1), (4, 7, 1), (1, 0, 1)])
+def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost):
+    env = dict(os.environ, RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "split_tiles_child.py")], env=env, capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in ("plain", "reflective", "bands"):
+        o = out[name]
+        assert o["tree_equals_brute"] and o["tree_equals_oracle"], (name, o)
+        assert o["rays"] == o["brute_rays"] == o["oracle_rays"], (name, o)
+    assert out["plain_f64_equal"] and out["reflective_f64_equal"]
