@@ -57,6 +57,10 @@ struct Context {
   size_t tile_list_cap = 0;
   long long plan_key[6] = {-1, -1, -1, -1, -1, -1};
   int plan_heavy = 0, plan_tiles = 0, plan_entries = 0;
+  /* frames issued on alternating streams overlap on the device: see plan_tiles */
+  hipStream_t last_stream = nullptr;
+  bool have_last_stream = false, frames_overlap = false;
+  int same_stream_calls = 0;
   unsigned long long scene_serial = 0;
   const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
   void* d_tri_primary = nullptr;
@@ -289,7 +293,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, Ren
   /* no rectangle (the camera is inside the bounds, say): every tile counts as a mesh tile */
   if (!have_rect && !by_xcd_wanted && (g.tri_rect.empty() || !g.crowded_first)) return RT_OK;
   const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
-                            g.light_per_block * 2 + (bvh ? 1 : 0)};
+                            g.light_per_block * 4 + (bvh ? 1 : 0) + (g.frames_overlap ? 2 : 0)};
   if (memcmp(key, g.plan_key, sizeof key) != 0) {
     std::vector<int32_t> heavy, light;
     for (int ty = 0; ty < tiles_y; ++ty) {
@@ -374,11 +378,13 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, Ren
      * long as its slowest wave, and a wave with fewer pixels walks less: 1080p lighthouse 65.9 -> 61.0 us,
      * 720p 82.7 -> 76.8 us, reflective 203 -> 192 us.  A launch with more tiles than that is bound by
      * throughput and pays for the idle lanes (4K lighthouse 150 -> 163 us): no split there.  Four parts for more
-     * than a few tiles push the crowded tiles into a second round (1080p: 79 us).  Tiles that fewer than 16
+     * than a few tiles push the crowded tiles into a second round (1080p: 79 us).  Frames that overlap on
+     * several streams fill the chip between them and are bound by throughput as well (lighthouse over 4
+     * streams: 39.7 us per frame whole, 48.0 split): no split while the caller alternates streams.  Tiles that fewer than 16
      * triangles project into are left whole: their walks are short, and halving them only costs lanes (the 12
      * triangles of the cube scene walked through a tree: 31 -> 41 us when split). */
     if (bvh && g.split_parts > 1 && g.split_tiles > 0 && !cost.empty() && !(by_xcd_wanted && heavy.size() >= 64) &&
-        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)4 * g.n_cu) {
+        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)4 * g.n_cu && !g.frames_overlap) {
       std::vector<int> sorted_cost(cost);
       std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<int>());
       const int floor_cost = std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)g.split_tiles - 1)]);
@@ -725,6 +731,16 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   if (p->accel == RT_ACCEL_AUTO && g.scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
   const bool count = p->count_rays != 0 && stats != nullptr;
   const bool reflect = g.reflective && p->max_depth >= 1;
+  /* A caller that moves from stream to stream has frames in flight side by side; 64 calls in a row on one
+   * stream end that assumption (each change of mind re-plans the tile list once). */
+  if (g.have_last_stream && s != g.last_stream) {
+    g.frames_overlap = true;
+    g.same_stream_calls = 0;
+  } else if (g.frames_overlap && ++g.same_stream_calls >= 64) {
+    g.frames_overlap = false;
+  }
+  g.last_stream = s;
+  g.have_last_stream = true;
   if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
     if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
