@@ -34,7 +34,7 @@ struct Context {
   bool use_lds = true;
   bool lds_stack = true;
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
-  int split_tiles = 256, split_parts = 2, split_min_cost = 16; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
+  int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
@@ -380,19 +380,26 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, Ren
      * throughput and pays for the idle lanes (4K lighthouse 150 -> 163 us): no split there.  Four parts for more
      * than a few tiles push the crowded tiles into a second round (1080p: 79 us).  Frames that overlap on
      * several streams fill the chip between them and are bound by throughput as well (lighthouse over 4
-     * streams: 39.7 us per frame whole, 48.0 split): no split while the caller alternates streams.  Tiles that fewer than 16
-     * triangles project into are left whole: their walks are short, and halving them only costs lanes (the 12
-     * triangles of the cube scene walked through a tree: 31 -> 41 us when split). */
+     * streams: 39.7 us per frame whole, 48.0 split): no split while the caller alternates streams.  Tiles that
+     * fewer than 16 triangles project into are left whole: their walks are short, and halving them only costs
+     * lanes (lighthouse with a floor of 8, 16, 24: 61.0, 61.5, 61.2 us; reflective 192, 195, 204 us). */
     if (bvh && g.split_parts > 1 && g.split_tiles > 0 && !cost.empty() && !(by_xcd_wanted && heavy.size() >= 64) &&
         n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)4 * g.n_cu && !g.frames_overlap) {
       std::vector<int> sorted_cost(cost);
       std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<int>());
       const int floor_cost = std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)g.split_tiles - 1)]);
+      /* the very first of them in four parts: few enough to stay in the first round (1080p lighthouse 61.9 ->
+       * 58.9 us, 720p 77.5 -> 69.0 us with 8; from 64 on the gain is gone) */
+      const int quarters = g.split_quarters;
+      const int floor_cost4 = quarters > 0 && g.split_parts == 2
+                                  ? std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)quarters - 1)])
+                                  : 0x7fffffff;
       std::vector<int32_t> split;
-      split.reserve(heavy.size() + (size_t)g.split_tiles * g.split_parts);
+      split.reserve(heavy.size() + (size_t)g.split_tiles * 4);
       for (int32_t tile : heavy) {
         if (cost_of_tile[tile] >= floor_cost) {
-          for (int part = 0; part < g.split_parts; ++part) split.push_back(tile | (part << 24) | (g.split_parts << 26));
+          const int parts = cost_of_tile[tile] >= floor_cost4 ? 4 : g.split_parts;
+          for (int part = 0; part < parts; ++part) split.push_back(tile | (part << 24) | (parts << 26));
         } else {
           split.push_back(tile);
         }
@@ -831,6 +838,7 @@ int rt_hip_init(int device) {
   g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("RT_HIP_CROWDED_FIRST")) g.crowded_first = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SPLIT_TILES")) g.split_tiles = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS")) g.split_quarters = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) g.split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) g.split_min_cost = atoi(e);
   if (const char* e = getenv("RT_HIP_XCD_TILES")) g.xcd_tiles = atoi(e) != 0 ? 1 : 0;
