@@ -228,7 +228,7 @@ void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t
   }
 }
 
-/* general 4x4 inverse (Gauss-Jordan, partial pivoting); only used for the scheduling hint below */
+/* general 4x4 inverse (Gauss-Jordan, partial pivoting); only used for scheduling hints and padding scales */
 bool invert4(const double* m, double* out) {
   double a[4][8];
   for (int r = 0; r < 4; ++r)
@@ -967,6 +967,17 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   for (int c = 0; c < 3; ++c) if (std::fabs(org[c]) > amax) amax = std::fabs(org[c]);
   amax = std::fmax(amax, std::fmax(std::fabs(sc->light.position[0]),
                                    std::fmax(std::fabs(sc->light.position[1]), std::fabs(sc->light.position[2]))));
+  /* rays that are walked through the tree also start on spheres (mirror and shadow rays): the single-precision
+   * box tests are padded relative to the largest coordinate a ray origin can have */
+  for (int i = 0; i < ns; ++i) {
+    double fwd[16];
+    if (!invert4(sc->sph_inv + 16 * (size_t)i, fwd)) continue;
+    for (int c = 0; c < 3; ++c) {
+      const double reach = std::fabs(fwd[4 * c + 3]) +
+                           std::sqrt(fwd[4 * c] * fwd[4 * c] + fwd[4 * c + 1] * fwd[4 * c + 1] + fwd[4 * c + 2] * fwd[4 * c + 2]);
+      if (std::isfinite(reach) && reach > amax) amax = reach;
+    }
+  }
   std::vector<DevSpherePrimary> hsp((size_t)(ns > 0 ? ns : 1));
   for (int i = 0; i < ns; ++i) {
     const double* m = hs[i].inv;

@@ -83,3 +83,29 @@ def test_rays_parallel_to_the_axes_through_the_bvh(hip, eye, to):
     hip.build_bvh_device(1)
     dev, sd = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
     assert np.array_equal(dev, want) and sd.rays == ost.rays
+
+
+def test_mirror_spheres_far_from_the_mesh(hip):
+    """Mirror and shadow rays that start on a sphere hundreds of units away are walked through the mesh's tree: the
+    padding of its single-precision boxes has to scale with where those rays start, not only with the mesh."""
+    from raytracer_amd.scene import SceneBuilder
+    from test_hip_parity import icosphere
+
+    b = SceneBuilder()
+    b.set_camera(96, 64, 0.5, (700.0, 40.0, -900.0), (250.0, 0.0, 0.0))
+    b.set_light((-300.0, 900.0, -700.0), (1, 1, 1))
+    b.add_triangles_f32(icosphere(3) * np.float32(60.0))
+    b.add_sphere(R.Mat4.mul(R.Mat4.translate(500.0, 0.0, 0.0), R.Mat4.scale(200.0, 200.0, 200.0)), R.default_material(reflective=0.9))
+    b.add_sphere(R.Mat4.mul(R.Mat4.translate(150.0, -400.0, 100.0), R.Mat4.scale(300.0, 300.0, 300.0)), R.default_material(reflective=0.5))
+    b.set_reflective(0.3, 0.8)
+    s = b.finish(2)
+    hip.upload(s)
+    tree, st = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    brute, sb = hip.render(accel=R._ffi.RT_ACCEL_BRUTE, count_rays=True)
+    want, ost = O.render_rgb(s)
+    assert O.probe().exact_zero_t == 0 and O.probe().list_overflow == 0
+    assert st.rays_secondary > 500 and tree.max() > 0
+    assert np.array_equal(tree, brute) and np.array_equal(tree, want) and st.rays == sb.rays == ost.rays
+    hip.build_bvh_device(2)
+    dev, sd = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True)
+    assert np.array_equal(dev, want) and sd.rays == ost.rays
