@@ -42,5 +42,13 @@ for name, w, h, refl, ranks in (("plain", 320, 200, 0.0, 1), ("reflective", 203,
             brute_rays += sb.rays
     out[name] = {"tree_equals_brute": bool(np.array_equal(tree, brute)), "tree_equals_oracle": bool(np.array_equal(tree, want)),
                  "rays": int(rays), "brute_rays": int(brute_rays), "oracle_rays": int(ost.rays)}
+# four samples per pixel, an image that does not fill its last tiles, the counting and the plain kernel
+s = R.stock_scene("lighthouse", 171, 99, tri_reflective=0.2)
+hip.upload(s)
+want, ost = O.render_rgb(s, spp_grid=2)
+tree, st = hip.render(accel=R._ffi.RT_ACCEL_BVH, count_rays=True, spp_grid=2)
+plain, _ = hip.render(accel=R._ffi.RT_ACCEL_BVH, spp_grid=2)
+out["supersampled"] = {"tree_equals_brute": bool(np.array_equal(tree, plain)), "tree_equals_oracle": bool(np.array_equal(tree, want)),
+                       "rays": int(st.rays), "brute_rays": int(ost.rays), "oracle_rays": int(ost.rays)}
 hip.shutdown()
 print(json.dumps(out))

@@ -19,7 +19,7 @@ def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost):
                        timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    for name in ("plain", "reflective", "bands"):
+    for name in ("plain", "reflective", "bands", "supersampled"):
         o = out[name]
         assert o["tree_equals_brute"] and o["tree_equals_oracle"], (name, o)
         assert o["rays"] == o["brute_rays"] == o["oracle_rays"], (name, o)
