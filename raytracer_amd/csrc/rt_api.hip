@@ -34,7 +34,7 @@ struct Context {
   bool use_lds = true;
   bool lds_stack = true;
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
-  int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
+  int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
@@ -275,7 +275,7 @@ bool mesh_pixel_rect(const rt_camera& cam, double& x0, double& y0, double& x1, d
 
 /* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
  * per workgroup).  Kept until the scene or the band layout changes. */
-int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, RenderArgs& a, int& n_blocks) {
+int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, hipStream_t s, RenderArgs& a, int& n_blocks) {
   const int W = g.scene.hsize;
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const int n_tiles = tiles_x * tiles_y;
@@ -293,7 +293,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, Ren
   /* no rectangle (the camera is inside the bounds, say): every tile counts as a mesh tile */
   if (!have_rect && !by_xcd_wanted && (g.tri_rect.empty() || !g.crowded_first)) return RT_OK;
   const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
-                            g.light_per_block * 4 + (bvh ? 1 : 0) + (g.frames_overlap ? 2 : 0)};
+                            g.light_per_block * 8 + (bvh ? 1 : 0) + (g.frames_overlap ? 2 : 0) + (reflect ? 4 : 0)};
   if (memcmp(key, g.plan_key, sizeof key) != 0) {
     std::vector<int32_t> heavy, light;
     for (int ty = 0; ty < tiles_y; ++ty) {
@@ -377,20 +377,23 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, hipStream_t s, Ren
      * whatever its lanes).  A launch whose mesh tiles are resident within two rounds of workgroups lasts as
      * long as its slowest wave, and a wave with fewer pixels walks less: 1080p lighthouse 65.9 -> 61.0 us,
      * 720p 82.7 -> 76.8 us, reflective 203 -> 192 us.  A launch with more tiles than that is bound by
-     * throughput and pays for the idle lanes (4K lighthouse 150 -> 163 us): no split there.  Four parts for more
+     * throughput and pays for the idle lanes (4K lighthouse 150 -> 163 us, with mirror bounces 223 -> 285 us,
+     * 1440p 219 -> 241 us): no split there.  Four parts for more
      * than a few tiles push the crowded tiles into a second round (1080p: 79 us).  Frames that overlap on
      * several streams fill the chip between them and are bound by throughput as well (lighthouse over 4
      * streams: 39.7 us per frame whole, 48.0 split): no split while the caller alternates streams.  Tiles that
      * fewer than 16 triangles project into are left whole: their walks are short, and halving them only costs
      * lanes (lighthouse with a floor of 8, 16, 24: 61.0, 61.5, 61.2 us; reflective 192, 195, 204 us). */
     if (bvh && g.split_parts > 1 && g.split_tiles > 0 && !cost.empty() && !(by_xcd_wanted && heavy.size() >= 64) &&
-        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)4 * g.n_cu && !g.frames_overlap) {
+        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)g.split_max_per_cu * g.n_cu && !g.frames_overlap) {
       std::vector<int> sorted_cost(cost);
       std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<int>());
       const int floor_cost = std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)g.split_tiles - 1)]);
       /* the very first of them in four parts: few enough to stay in the first round (1080p lighthouse 61.9 ->
-       * 58.9 us, 720p 77.5 -> 69.0 us with 8; from 64 on the gain is gone) */
-      const int quarters = g.split_quarters;
+       * 58.9 us, 720p 77.5 -> 69.0 us with 8; from 64 on the gain is gone).  With mirror bounces a wave lasts
+       * several times longer and the extra workgroups weigh less: 128 there (720p / 900p / 1080p: 181 / 220 /
+       * 197 us with 8, 176 / 176 / 188 us with 128; whole tiles: 203 / 237 / 208 us). */
+      const int quarters = reflect ? g.split_quarters_reflect : g.split_quarters;
       const int floor_cost4 = quarters > 0 && g.split_parts == 2
                                   ? std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)quarters - 1)])
                                   : 0x7fffffff;
@@ -763,7 +766,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
       const int prc = plan_general_tiles(p, rows, s, a);
       if (prc != RT_OK) return prc;
     } else {
-      const int prc = plan_tiles(p, rows, bvh, s, a, n_blocks);
+      const int prc = plan_tiles(p, rows, bvh, reflect, s, a, n_blocks);
       if (prc != RT_OK) return prc;
     }
     (void)n_tiles;
@@ -839,6 +842,8 @@ int rt_hip_init(int device) {
   if (const char* e = getenv("RT_HIP_CROWDED_FIRST")) g.crowded_first = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SPLIT_TILES")) g.split_tiles = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS")) g.split_quarters = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_MAX_PER_CU")) g.split_max_per_cu = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS_REFLECT")) g.split_quarters_reflect = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) g.split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) g.split_min_cost = atoi(e);
   if (const char* e = getenv("RT_HIP_XCD_TILES")) g.xcd_tiles = atoi(e) != 0 ? 1 : 0;
