@@ -106,7 +106,7 @@ def pipelined_measurements(hip, dev, streams=4, steps=300):
         hip.upload(R.stock_scene(scene, WIDTH, HEIGHT, tr))
         st = R._ffi.Stats()
         hip.render_device(bufs[0].data_ptr(), R.make_params(accel=accel, count_rays=True), stats=st)
-        p = R.make_params(accel=accel)
+        p = R.make_params(accel=accel, frames_overlap=True)
         best = None
         for rep in range(3):
             for i in range(2 * streams):

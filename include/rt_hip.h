@@ -19,9 +19,11 @@
  * entry points.
  *
  * All entry points return RT_OK (0) or a negative rt_status; none aborts.
- * The library keeps one context per process (the reference itself is a
- * single global `canvas`/`contents`, RayTracer.c:102,255) and is not
- * re-entrant: one process drives one GPU.
+ * The library keeps one context per HIP device of the process (scene, stream,
+ * buffers); rt_hip_init / rt_hip_set_device choose the one the other entry
+ * points act on, and the rt_hip_multi_* entry points drive several at once.
+ * Like the reference (a single global `canvas`/`contents`,
+ * RayTracer.c:102,255) it is not re-entrant: one host thread at a time.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -187,8 +189,18 @@ typedef struct rt_render_params {
   int32_t band_rows;    /* rows per band (>= 1); ignored when n_ranks == 1      */
   int32_t n_ranks;      /* >= 1                                                  */
   int32_t rank;         /* 0 .. n_ranks-1                                        */
-  int32_t reserved;
+  int32_t flags;        /* RT_RENDER_* bits, 0 = none                            */
 } rt_render_params;
+
+/* rt_render_params.flags */
+enum {
+  /* The caller keeps several frames in flight at once (rt_hip_render_device on
+   * more than one stream).  Such frames fill the GPU between them, so the
+   * launch is planned for throughput: no tile is split over several
+   * workgroups to shorten a lone frame's slowest wave.  Images are the same
+   * either way. */
+  RT_RENDER_FRAMES_OVERLAP = 1
+};
 
 typedef struct rt_stats {
   uint64_t rays_primary;    /* ray_for_pixel calls                               */
@@ -202,9 +214,14 @@ typedef struct rt_stats {
   int32_t accel_used;       /* RT_ACCEL_BRUTE, RT_ACCEL_BVH or RT_ACCEL_REFERENCE */
 } rt_stats;
 
-/* Bind the process to HIP device `device` and create the stream and events.
- * Replaces nothing in the reference (it has no device); call once. */
+/* Create the context of HIP device `device` (stream, events) if it does not
+ * exist yet and make it the current one.  Replaces nothing in the reference
+ * (it has no device).  Contexts of other devices stay as they are. */
 int rt_hip_init(int device);
+
+/* Make the context of an initialised device the current one (also makes the
+ * device current for the calling thread's HIP calls). */
+int rt_hip_set_device(int device);
 
 /* Copy the flattened world + camera + light to the device.  Replaces the
  * pointer arguments of render(camera*, world*), RayTracer.c:1574: the scene
@@ -262,7 +279,8 @@ size_t rt_hip_ppm_capacity(int width, int height);
  * rt_hip_ppm_capacity() bytes of device memory, 16-byte aligned.  Enqueued on
  * `stream` (NULL = the library's).  bytes_out != NULL: waits and stores the
  * length of the text; NULL: returns at once (the length can be had later from
- * rt_hip_ppm_last_length, which waits). */
+ * rt_hip_ppm_last_length, which waits).  Calls share library-owned length
+ * arrays: a call on another stream than the previous one is ordered after it. */
 int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void* text_device, size_t capacity,
                              size_t* bytes_out, void* stream);
 int rt_hip_ppm_last_length(size_t* bytes_out);
@@ -292,7 +310,7 @@ int rt_hip_rank_row_to_y(int i, int band_rows, int n_ranks, int rank);
 int rt_hip_event_record(int which, void* stream);
 int rt_hip_event_elapsed_ms(double* ms_out);
 
-/* Release device memory, stream and events. */
+/* Release device memory, streams and events of every context. */
 void rt_hip_shutdown(void);
 
 const char* rt_hip_strerror(int status);

@@ -22,6 +22,8 @@ RT_ACCEL_BRUTE = 1
 RT_ACCEL_BVH = 2
 RT_ACCEL_REFERENCE = 3
 
+RT_RENDER_FRAMES_OVERLAP = 1
+
 
 class Material(C.Structure):
     _fields_ = [
@@ -119,7 +121,7 @@ class RenderParams(C.Structure):
         ("band_rows", C.c_int32),
         ("n_ranks", C.c_int32),
         ("rank", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -214,6 +216,7 @@ def hip_lib():
             pass
         L = C.CDLL(path)
         L.rt_hip_init.argtypes = [C.c_int]
+        L.rt_hip_set_device.argtypes = [C.c_int]
         L.rt_hip_upload_scene.argtypes = [C.POINTER(Scene)]
         L.rt_hip_build_bvh_device.argtypes = [C.c_int, C.POINTER(BvhDeviceInfo)]
         L.rt_hip_render.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
@@ -241,6 +244,7 @@ def hip_lib():
 
 HIP_EXPORTS = [
     "rt_hip_init",
+    "rt_hip_set_device",
     "rt_hip_upload_scene",
     "rt_hip_build_bvh_device",
     "rt_hip_render",

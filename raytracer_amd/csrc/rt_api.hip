@@ -52,15 +52,18 @@ struct Context {
   double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
   double box_pad = 0.0; /* what every single-precision box is grown by */
   std::vector<float> tri_rect; /* pixel rectangle (x0 y0 x1 y1) of every triangle as the camera sees it; empty: unknown */
-  /* tile order of the last plan and the parameters it was made for */
-  int32_t* d_tile_list = nullptr;
-  size_t tile_list_cap = 0;
-  long long plan_key[6] = {-1, -1, -1, -1, -1, -1};
-  int plan_heavy = 0, plan_tiles = 0, plan_entries = 0;
-  /* frames issued on alternating streams overlap on the device: see plan_tiles */
-  hipStream_t last_stream = nullptr;
-  bool have_last_stream = false, frames_overlap = false;
-  int same_stream_calls = 0;
+  /* tile orders of recent launches and the parameters each was made for (scene, bands, kernel family, overlap
+   * mode): a caller that alternates between a few kinds of launch does not re-plan every time */
+  struct TilePlan {
+    long long key[6] = {-1, -1, -1, -1, -1, -1};
+    int32_t* d_list = nullptr;
+    size_t cap = 0;
+    int heavy = 0, tiles = 0, entries = 0;
+    unsigned long long last_use = 0;
+  };
+  static constexpr int kPlans = 4;
+  TilePlan plans[kPlans];
+  unsigned long long plan_clock = 0;
   unsigned long long scene_serial = 0;
   const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
   void* d_tri_primary = nullptr;
@@ -87,9 +90,14 @@ struct Context {
   unsigned long long* d_ppm_total_host = nullptr; /* the same word as the device addresses it */
   hipStream_t ppm_stream = nullptr;          /* stream of the last formatting call */
   bool ppm_pending = false;
+  hipEvent_t ppm_ev = nullptr;               /* orders formatting calls on different streams: they share the arrays above */
 };
 
-Context g;
+/* One context per HIP device of this process; `cur` is the one the entry points act on (rt_hip_init and
+ * rt_hip_set_device choose it). */
+constexpr int kMaxDevices = 16;
+Context g_ctx[kMaxDevices];
+Context* cur = &g_ctx[0];
 char g_err[512] = "";
 
 bool hip_ok(hipError_t e, const char* what) {
@@ -103,26 +111,26 @@ bool hip_ok(hipError_t e, const char* what) {
   } while (0)
 
 void free_general() {
-  if (g.d_gen_scene) (void)hipFree(g.d_gen_scene);
-  if (g.d_gen_objects) (void)hipFree(g.d_gen_objects);
-  if (g.d_gen_materials) (void)hipFree(g.d_gen_materials);
-  g.d_gen_scene = nullptr;
-  g.d_gen_objects = nullptr;
-  g.d_gen_materials = nullptr;
-  g.general = false;
+  if (cur->d_gen_scene) (void)hipFree(cur->d_gen_scene);
+  if (cur->d_gen_objects) (void)hipFree(cur->d_gen_objects);
+  if (cur->d_gen_materials) (void)hipFree(cur->d_gen_materials);
+  cur->d_gen_scene = nullptr;
+  cur->d_gen_objects = nullptr;
+  cur->d_gen_materials = nullptr;
+  cur->general = false;
 }
 
 void free_scene() {
   free_general();
-  if (g.d_spheres) (void)hipFree(g.d_spheres);
-  if (g.d_tris) (void)hipFree(g.d_tris);
-  if (g.d_normals) (void)hipFree(g.d_normals);
-  if (g.d_materials) (void)hipFree(g.d_materials);
-  if (g.d_bvh) (void)hipFree(g.d_bvh);
-  if (g.d_tri_primary) (void)hipFree(g.d_tri_primary);
-  if (g.d_sph_primary) (void)hipFree(g.d_sph_primary);
-  g.d_spheres = g.d_tris = g.d_normals = g.d_materials = g.d_bvh = g.d_tri_primary = g.d_sph_primary = nullptr;
-  g.have_scene = false;
+  if (cur->d_spheres) (void)hipFree(cur->d_spheres);
+  if (cur->d_tris) (void)hipFree(cur->d_tris);
+  if (cur->d_normals) (void)hipFree(cur->d_normals);
+  if (cur->d_materials) (void)hipFree(cur->d_materials);
+  if (cur->d_bvh) (void)hipFree(cur->d_bvh);
+  if (cur->d_tri_primary) (void)hipFree(cur->d_tri_primary);
+  if (cur->d_sph_primary) (void)hipFree(cur->d_sph_primary);
+  cur->d_spheres = cur->d_tris = cur->d_normals = cur->d_materials = cur->d_bvh = cur->d_tri_primary = cur->d_sph_primary = nullptr;
+  cur->have_scene = false;
 }
 
 int upload(void** dst, const void* src, size_t bytes) {
@@ -149,83 +157,69 @@ constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their t
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
 
-template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT, int KIND>
-void launch_stage(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
-                  double* canvas) {
-  const dim3 block(RT_TILE_W * RT_TILE_H);
-  if (stage == 0)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, 0, KIND>), grid, block, 0, s, g.d_scene, (const DevSphere*)g.d_spheres,
-                       (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list,
-                       rgb, canvas, g.d_counters);
-  else if (BVH && stage == 4)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 4 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
-  else if (BVH && stage == 3)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 3 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
-  else if (BVH)
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 2 : 0, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
-  else
-    hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1, KIND>), grid, block, lds, s, g.d_scene,
-                       (const DevSphere*)g.d_spheres, (const DevSpherePrimary*)g.d_sph_primary, (const DevTri*)g.d_tris, (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const rt_material*)g.d_materials, (const DevBvh2*)g.d_bvh, a, g.launch_tile_list, rgb, canvas, g.d_counters);
+template <bool COUNT, bool BVH, bool REFLECT, int STAGE, int KIND>
+void launch_one(size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, STAGE, KIND>), grid, dim3(RT_TILE_W * RT_TILE_H), lds, s, cur->d_scene,
+                     (const DevSphere*)cur->d_spheres, (const DevSpherePrimary*)cur->d_sph_primary, (const DevTri*)cur->d_tris,
+                     (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const rt_material*)cur->d_materials,
+                     (const DevBvh2*)cur->d_bvh, a, cur->launch_tile_list, rgb, canvas, cur->d_counters);
 }
-template <bool COUNT, bool BVH, bool REFLECT, bool F64OUT>
-void launch_kind(int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
-                 double* canvas) {
-  /* kernels specialised for the primitive kinds the scene holds; the BVH kernels always have triangles */
-  if (!BVH && g.scene.n_tris == 0)
-    launch_stage<COUNT, BVH, REFLECT, F64OUT, BVH ? 0 : 1>(stage, lds, grid, s, a, rgb, canvas);
-  else if (g.scene.n_spheres == 0)
-    launch_stage<COUNT, BVH, REFLECT, F64OUT, 2>(stage, lds, grid, s, a, rgb, canvas);
-  else
-    launch_stage<COUNT, BVH, REFLECT, F64OUT, 0>(stage, lds, grid, s, a, rgb, canvas);
+/* kernels specialised for the primitive kinds the scene holds (KIND 1: spheres only, 2: triangles only, 0: both) */
+template <bool BVH, bool REFLECT, int STAGE>
+void launch_kind(int kind, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  if (kind == 2) launch_one<false, BVH, REFLECT, STAGE, 2>(lds, grid, s, a, rgb, canvas);
+  else launch_one<false, BVH, REFLECT, STAGE, 0>(lds, grid, s, a, rgb, canvas);
 }
-template <bool COUNT, bool BVH, bool REFLECT>
-void launch_f64(bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
-                double* canvas) {
-  if (f64) launch_kind<COUNT, BVH, REFLECT, true>(stage, lds, grid, s, a, rgb, canvas);
-  else launch_kind<COUNT, BVH, REFLECT, false>(stage, lds, grid, s, a, rgb, canvas);
+template <bool REFLECT>
+void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+                   double* canvas) {
+  if (bvh) { /* a walk always has triangles */
+    if (stage == 3) launch_kind<true, REFLECT, 3>(kind, lds, grid, s, a, rgb, canvas);
+    else if (stage == 4) launch_kind<true, REFLECT, 4>(kind, lds, grid, s, a, rgb, canvas);
+    else launch_kind<true, REFLECT, 0>(kind, 0, grid, s, a, rgb, canvas);
+  } else if (kind == 1) {
+    launch_one<false, false, REFLECT, 0, 1>(0, grid, s, a, rgb, canvas);
+  } else if (stage == 1) {
+    launch_kind<false, REFLECT, 1>(kind, lds, grid, s, a, rgb, canvas);
+  } else {
+    launch_kind<false, REFLECT, 0>(kind, 0, grid, s, a, rgb, canvas);
+  }
 }
-template <bool COUNT, bool BVH>
-void launch_refl(bool reflect, bool f64, int stage, size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a,
-                 unsigned char* rgb, double* canvas) {
-  if (reflect) launch_f64<COUNT, BVH, true>(f64, stage, lds, grid, s, a, rgb, canvas);
-  else launch_f64<COUNT, BVH, false>(f64, stage, lds, grid, s, a, rgb, canvas);
-}
-void launch(bool count, bool bvh, bool reflect, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a,
-            unsigned char* rgb, double* canvas) {
+void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+            double* canvas) {
+  /* The counting build exists once per family: what it counts (rays, tests) does not depend on where the
+   * primitives are staged, on the kinds present or on whether any material reflects. */
+  if (count) {
+    if (bvh) launch_one<true, true, true, 0, 0>(0, grid, s, a, rgb, canvas);
+    else launch_one<true, false, true, 0, 0>(0, grid, s, a, rgb, canvas);
+    return;
+  }
   int stage = 0;
   size_t lds = 0;
-  if (g.use_lds) {
-    if (!bvh && g.scene.n_tris > 0 && g.scene.n_tris <= kMaxLdsTris) {
+  if (cur->use_lds) {
+    if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
       stage = 1;
-      lds = (size_t)g.scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
-    } else if (bvh) {
-      if (g.scene.n_bvh_nodes <= kMaxLdsBvhNodes) {
-        stage = 2;
-        lds = (size_t)g.scene.n_bvh_nodes * sizeof(DevBvh2);
-      }
-      /* the traversal stacks too (for a large tree: the stacks alone), while two workgroups still fit a CU's
-       * 160 KiB (the walk's register budget allows no more than two anyway) */
-      const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)g.scene.bvh_depth;
-      /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
-       * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
-       * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
-      const size_t room = stage == 2 || reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3;
-      if (g.lds_stack && g.scene.bvh_depth >= 1 && lds + stacks <= room) {
-        stage = stage == 2 ? 3 : 4;
-        lds += stacks;
+      lds = (size_t)cur->scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
+    } else if (bvh && cur->lds_stack && cur->scene.bvh_depth >= 1) {
+      /* the traversal stacks, and in front of them the inner nodes if both fit while two workgroups still share
+       * a CU's 160 KiB (the walk's register budget allows no more than two anyway) */
+      const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)cur->scene.bvh_depth;
+      const size_t nodes = (size_t)cur->scene.n_bvh_nodes * sizeof(DevBvh2);
+      if (cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
+        stage = 3;
+        lds = nodes + stacks;
+      } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3)) {
+        /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
+         * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
+         * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
+        stage = 4;
+        lds = stacks;
       }
     }
   }
-  if (count) {
-    if (bvh) launch_refl<true, true>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
-    else launch_refl<true, false>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
-  } else {
-    if (bvh) launch_refl<false, true>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
-    else launch_refl<false, false>(reflect, f64, stage, lds, grid, s, a, rgb, canvas);
-  }
+  const int kind = (!bvh && cur->scene.n_tris == 0) ? 1 : (cur->scene.n_spheres == 0 ? 2 : 0);
+  if (reflect) launch_family<true>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
+  else launch_family<false>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
 }
 
 /* general 4x4 inverse (Gauss-Jordan, partial pivoting); only used for scheduling hints and padding scales */
@@ -259,8 +253,8 @@ bool mesh_pixel_rect(const rt_camera& cam, double& x0, double& y0, double& x1, d
   x0 = y0 = 1e300;
   x1 = y1 = -1e300;
   for (int k = 0; k < 8; ++k) {
-    const double w[3] = {(k & 1) ? g.mesh_hi[0] : g.mesh_lo[0], (k & 2) ? g.mesh_hi[1] : g.mesh_lo[1],
-                         (k & 4) ? g.mesh_hi[2] : g.mesh_lo[2]};
+    const double w[3] = {(k & 1) ? cur->mesh_hi[0] : cur->mesh_lo[0], (k & 2) ? cur->mesh_hi[1] : cur->mesh_lo[1],
+                         (k & 4) ? cur->mesh_hi[2] : cur->mesh_lo[2]};
     double c[3];
     for (int r = 0; r < 3; ++r) c[r] = view[4 * r] * w[0] + view[4 * r + 1] * w[1] + view[4 * r + 2] * w[2] + view[4 * r + 3];
     if (!(c[2] < -1e-6)) return false;
@@ -273,28 +267,64 @@ bool mesh_pixel_rect(const rt_camera& cam, double& x0, double& y0, double& x1, d
   return std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1);
 }
 
+/* The cached tile plan for `key`, or the least recently used slot with `fresh` set.  Launches still in flight
+ * (on any stream) may read the list of a slot that is about to be rewritten, so eviction waits for the device;
+ * a slot that was never used needs no wait. */
+Context::TilePlan* find_plan(const long long key[6], bool& fresh) {
+  Context::TilePlan* victim = &cur->plans[0];
+  for (Context::TilePlan& t : cur->plans) {
+    if (memcmp(key, t.key, sizeof t.key) == 0) {
+      fresh = false;
+      t.last_use = ++cur->plan_clock;
+      return &t;
+    }
+    if (t.last_use < victim->last_use) victim = &t;
+  }
+  fresh = true;
+  return victim;
+}
+/* fill an evicted slot with `list` */
+int store_plan(Context::TilePlan* t, const long long key[6], const std::vector<int32_t>& list, hipStream_t s) {
+  if (t->last_use != 0) HIP_TRY(hipDeviceSynchronize());
+  t->key[0] = -1;
+  if (list.size() > t->cap) {
+    if (t->d_list) (void)hipFree(t->d_list);
+    t->d_list = nullptr;
+    t->cap = 0;
+    HIP_TRY(hipMalloc((void**)&t->d_list, sizeof(int32_t) * list.size()));
+    t->cap = list.size();
+  }
+  HIP_TRY(hipMemcpyAsync(t->d_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
+  memcpy(t->key, key, sizeof t->key);
+  t->last_use = ++cur->plan_clock;
+  return RT_OK;
+}
+
 /* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
  * per workgroup).  Kept until the scene or the band layout changes. */
-int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, hipStream_t s, RenderArgs& a, int& n_blocks) {
-  const int W = g.scene.hsize;
+int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool overlap, hipStream_t s, RenderArgs& a, int& n_blocks) {
+  const int W = cur->scene.hsize;
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const int n_tiles = tiles_x * tiles_y;
-  g.launch_tile_list = nullptr;
+  cur->launch_tile_list = nullptr;
   a.n_heavy = n_tiles;
   a.light_per_block = 1;
   a.n_entries = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
   /* with spheres in the world any pixel may be expensive; without triangles there is nothing to sort by */
-  if (!g.tile_plan || g.scene.n_tris == 0 || g.light_per_block <= 1) return RT_OK;
-  const bool tree_in_memory = g.scene.n_bvh_nodes > kMaxLdsBvhNodes;
-  const bool by_xcd_wanted = g.xcd_tiles == 1 || (g.xcd_tiles < 0 && tree_in_memory);
-  const bool have_rect = g.scene.n_spheres == 0 && mesh_pixel_rect(g.host_camera, x0, y0, x1, y1);
+  if (!cur->tile_plan || cur->scene.n_tris == 0 || cur->light_per_block <= 1) return RT_OK;
+  const bool tree_in_memory = cur->scene.n_bvh_nodes > kMaxLdsBvhNodes;
+  const bool by_xcd_wanted = cur->xcd_tiles == 1 || (cur->xcd_tiles < 0 && tree_in_memory);
+  const bool have_rect = cur->scene.n_spheres == 0 && mesh_pixel_rect(cur->host_camera, x0, y0, x1, y1);
   /* no rectangle (the camera is inside the bounds, say): every tile counts as a mesh tile */
-  if (!have_rect && !by_xcd_wanted && (g.tri_rect.empty() || !g.crowded_first)) return RT_OK;
-  const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
-                            g.light_per_block * 8 + (bvh ? 1 : 0) + (g.frames_overlap ? 2 : 0) + (reflect ? 4 : 0)};
-  if (memcmp(key, g.plan_key, sizeof key) != 0) {
+  if (!have_rect && !by_xcd_wanted && (cur->tri_rect.empty() || !cur->crowded_first)) return RT_OK;
+  const long long key[6] = {(long long)cur->scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
+                            cur->light_per_block * 8 + (bvh ? 1 : 0) + (overlap ? 2 : 0) + (reflect ? 4 : 0)};
+  bool fresh = false;
+  Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh) {
     std::vector<int32_t> heavy, light;
     for (int ty = 0; ty < tiles_y; ++ty) {
       /* image rows covered by this tile row (bands make packed rows non-contiguous in y) */
@@ -314,13 +344,13 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, hipS
      * ends when its last wave does.  Count, per 16 x 16 cell of the image, the triangles whose pixel rectangle
      * touches it; the mesh tiles start in descending order of that count. */
     std::vector<int> cost, cost_of_tile; /* by position in `heavy` (raster order); by tile number */
-    if (g.crowded_first && !g.tri_rect.empty() && heavy.size() > 1) {
-      const int cells_y = (g.scene.vsize + RT_TILE_H - 1) / RT_TILE_H;
+    if (cur->crowded_first && !cur->tri_rect.empty() && heavy.size() > 1) {
+      const int cells_y = (cur->scene.vsize + RT_TILE_H - 1) / RT_TILE_H;
       std::vector<int> crowd((size_t)tiles_x * cells_y, 0);
-      const size_t n_rect = g.tri_rect.size() / 4;
+      const size_t n_rect = cur->tri_rect.size() / 4;
       for (size_t k = 0; k < n_rect; ++k) {
-        const float* q = &g.tri_rect[4 * k];
-        if (!(q[2] >= 0.f && q[3] >= 0.f && q[0] < (float)W && q[1] < (float)g.scene.vsize)) continue;
+        const float* q = &cur->tri_rect[4 * k];
+        if (!(q[2] >= 0.f && q[3] >= 0.f && q[0] < (float)W && q[1] < (float)cur->scene.vsize)) continue;
         const int cx0 = std::max(0, (int)(q[0] / RT_TILE_W)), cx1 = std::min(tiles_x - 1, (int)(q[2] / RT_TILE_W));
         const int cy0 = std::max(0, (int)(q[1] / RT_TILE_H)), cy1 = std::min(cells_y - 1, (int)(q[3] / RT_TILE_H));
         if ((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 4096) continue; /* a triangle across the whole image says nothing */
@@ -384,24 +414,24 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, hipS
      * streams: 39.7 us per frame whole, 48.0 split): no split while the caller alternates streams.  Tiles that
      * fewer than 16 triangles project into are left whole: their walks are short, and halving them only costs
      * lanes (lighthouse with a floor of 8, 16, 24: 61.0, 61.5, 61.2 us; reflective 192, 195, 204 us). */
-    if (bvh && g.split_parts > 1 && g.split_tiles > 0 && !cost.empty() && !(by_xcd_wanted && heavy.size() >= 64) &&
-        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)g.split_max_per_cu * g.n_cu && !g.frames_overlap) {
+    if (bvh && cur->split_parts > 1 && cur->split_tiles > 0 && !cost.empty() && !(by_xcd_wanted && heavy.size() >= 64) &&
+        n_tiles <= RT_TILE_MASK && heavy.size() <= (size_t)cur->split_max_per_cu * cur->n_cu && !overlap) {
       std::vector<int> sorted_cost(cost);
       std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<int>());
-      const int floor_cost = std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)g.split_tiles - 1)]);
+      const int floor_cost = std::max(cur->split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)cur->split_tiles - 1)]);
       /* the very first of them in four parts: few enough to stay in the first round (1080p lighthouse 61.9 ->
        * 58.9 us, 720p 77.5 -> 69.0 us with 8; from 64 on the gain is gone).  With mirror bounces a wave lasts
        * several times longer and the extra workgroups weigh less: 128 there (720p / 900p / 1080p: 181 / 220 /
        * 197 us with 8, 176 / 176 / 188 us with 128; whole tiles: 203 / 237 / 208 us). */
-      const int quarters = reflect ? g.split_quarters_reflect : g.split_quarters;
-      const int floor_cost4 = quarters > 0 && g.split_parts == 2
-                                  ? std::max(g.split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)quarters - 1)])
+      const int quarters = reflect ? cur->split_quarters_reflect : cur->split_quarters;
+      const int floor_cost4 = quarters > 0 && cur->split_parts == 2
+                                  ? std::max(cur->split_min_cost, sorted_cost[std::min(sorted_cost.size() - 1, (size_t)quarters - 1)])
                                   : 0x7fffffff;
       std::vector<int32_t> split;
-      split.reserve(heavy.size() + (size_t)g.split_tiles * 4);
+      split.reserve(heavy.size() + (size_t)cur->split_tiles * 4);
       for (int32_t tile : heavy) {
         if (cost_of_tile[tile] >= floor_cost) {
-          const int parts = cost_of_tile[tile] >= floor_cost4 ? 4 : g.split_parts;
+          const int parts = cost_of_tile[tile] >= floor_cost4 ? 4 : cur->split_parts;
           for (int part = 0; part < parts; ++part) split.push_back(tile | (part << 24) | (parts << 26));
         } else {
           split.push_back(tile);
@@ -409,28 +439,18 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, hipS
       }
       heavy.swap(split);
     }
-    g.plan_heavy = (int)heavy.size();
-    g.plan_tiles = n_tiles;
+    plan->heavy = (int)heavy.size();
+    plan->tiles = n_tiles;
     heavy.insert(heavy.end(), light.begin(), light.end());
-    g.plan_entries = (int)heavy.size();
-    /* launches still in flight on other streams read the list that is about to change */
-    HIP_TRY(hipDeviceSynchronize());
-    if (heavy.size() > g.tile_list_cap) {
-      if (g.d_tile_list) (void)hipFree(g.d_tile_list);
-      g.d_tile_list = nullptr;
-      g.tile_list_cap = 0;
-      HIP_TRY(hipMalloc((void**)&g.d_tile_list, sizeof(int32_t) * heavy.size()));
-      g.tile_list_cap = heavy.size();
-    }
-    HIP_TRY(hipMemcpyAsync(g.d_tile_list, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
-    memcpy(g.plan_key, key, sizeof key);
+    plan->entries = (int)heavy.size();
+    const int src = store_plan(plan, key, heavy, s);
+    if (src != RT_OK) return src;
   }
-  g.launch_tile_list = g.d_tile_list;
-  a.n_heavy = g.plan_heavy;
-  a.light_per_block = g.light_per_block;
-  a.n_entries = g.plan_entries;
-  n_blocks = g.plan_heavy + (g.plan_entries - g.plan_heavy + g.light_per_block - 1) / g.light_per_block;
+  cur->launch_tile_list = plan->d_list;
+  a.n_heavy = plan->heavy;
+  a.light_per_block = cur->light_per_block;
+  a.n_entries = plan->entries;
+  n_blocks = plan->heavy + (plan->entries - plan->heavy + cur->light_per_block - 1) / cur->light_per_block;
   return RT_OK;
 }
 
@@ -600,65 +620,61 @@ int upload_general(const rt_scene* sc, bool only_form) {
 
   if (only_form) free_scene();
   else free_general();
-  HIP_TRY(hipMalloc((void**)&g.d_gen_scene, sizeof hd));
-  HIP_TRY(hipMemcpy(g.d_gen_scene, &hd, sizeof hd, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&g.d_gen_objects, sizeof(GenObject) * objs.size()));
-  HIP_TRY(hipMemcpy(g.d_gen_objects, objs.data(), sizeof(GenObject) * objs.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&g.d_gen_materials, sizeof(GenMaterial) * mats.size()));
-  HIP_TRY(hipMemcpy(g.d_gen_materials, mats.data(), sizeof(GenMaterial) * mats.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&cur->d_gen_scene, sizeof hd));
+  HIP_TRY(hipMemcpy(cur->d_gen_scene, &hd, sizeof hd, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&cur->d_gen_objects, sizeof(GenObject) * objs.size()));
+  HIP_TRY(hipMemcpy(cur->d_gen_objects, objs.data(), sizeof(GenObject) * objs.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&cur->d_gen_materials, sizeof(GenMaterial) * mats.size()));
+  HIP_TRY(hipMemcpy(cur->d_gen_materials, mats.data(), sizeof(GenMaterial) * mats.size(), hipMemcpyHostToDevice));
   /* a short list when no ray can fill it; otherwise the reference's 100 slots, overflow behaviour included */
-  g.gen_list_cap = max_entries <= 32 ? 32 : 100;
+  cur->gen_list_cap = max_entries <= 32 ? 32 : 100;
   if (!only_form) return RT_OK; /* the scene also has its sphere / triangle form; RT_ACCEL_REFERENCE selects this one */
-  g.general = true;
-  g.scene = DevScene{};
-  g.scene.hsize = sc->camera.hsize;
-  g.scene.vsize = sc->camera.vsize;
-  g.host_camera = sc->camera;
-  g.reflective = false;
-  g.have_scene = true;
-  ++g.scene_serial;
+  cur->general = true;
+  cur->scene = DevScene{};
+  cur->scene.hsize = sc->camera.hsize;
+  cur->scene.vsize = sc->camera.vsize;
+  cur->host_camera = sc->camera;
+  cur->reflective = false;
+  cur->have_scene = true;
+  ++cur->scene_serial;
   return RT_OK;
 }
 
-template <bool COUNT, bool F64OUT>
+template <bool COUNT>
 void launch_general_cap(dim3 grid, hipStream_t s, const RenderArgs& a, const int32_t* tile_list, int32_t* probe_cost,
                         unsigned char* rgb, double* canvas) {
   const dim3 block(RT_TILE_W * RT_TILE_H);
-  if (g.gen_list_cap <= 32)
-    hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 32>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
-                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, tile_list, probe_cost, rgb,
-                       canvas, g.d_counters);
+  if (cur->gen_list_cap <= 32)
+    hipLaunchKernelGGL((rt_general_kernel<COUNT, 32>), grid, block, 0, s, (const GenScene*)cur->d_gen_scene,
+                       (const GenObject*)cur->d_gen_objects, (const GenMaterial*)cur->d_gen_materials, a, tile_list, probe_cost, rgb,
+                       canvas, cur->d_counters);
   else
-    hipLaunchKernelGGL((rt_general_kernel<COUNT, F64OUT, 100>), grid, block, 0, s, (const GenScene*)g.d_gen_scene,
-                       (const GenObject*)g.d_gen_objects, (const GenMaterial*)g.d_gen_materials, a, tile_list, probe_cost, rgb,
-                       canvas, g.d_counters);
+    hipLaunchKernelGGL((rt_general_kernel<COUNT, 100>), grid, block, 0, s, (const GenScene*)cur->d_gen_scene,
+                       (const GenObject*)cur->d_gen_objects, (const GenMaterial*)cur->d_gen_materials, a, tile_list, probe_cost, rgb,
+                       canvas, cur->d_counters);
 }
-void launch_general(bool count, bool f64, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
-  if (count) {
-    if (f64) launch_general_cap<true, true>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
-    else launch_general_cap<true, false>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
-  } else {
-    if (f64) launch_general_cap<false, true>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
-    else launch_general_cap<false, false>(grid, s, a, g.launch_tile_list, nullptr, rgb, canvas);
-  }
+void launch_general(bool count, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
+  if (count) launch_general_cap<true>(grid, s, a, cur->launch_tile_list, nullptr, rgb, canvas);
+  else launch_general_cap<false>(grid, s, a, cur->launch_tile_list, nullptr, rgb, canvas);
 }
 
 /* Tile order for launches of the general kernel.  What a tile costs there is the size of its pixels' ray trees
  * (mirrors and glass, also on planes that no pixel rectangle bounds), so it is measured: one small launch traces
  * four pixels of every tile and counts their rays, and the tiles then start, block by block, in descending order
  * of that count.
- * Kept, like plan_tiles' list and in the same buffer, until the scene, the band layout or the depth changes. */
+ * Kept in the same plan cache as plan_tiles' lists, keyed by scene, band layout and depth. */
 int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const RenderArgs& a) {
-  g.launch_tile_list = nullptr;
-  if (!g.tile_plan) return RT_OK;
-  const int tiles_x = (g.scene.hsize + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+  cur->launch_tile_list = nullptr;
+  if (!cur->tile_plan) return RT_OK;
+  const int tiles_x = (cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const long long n_tiles_ll = (long long)tiles_x * tiles_y;
   if (n_tiles_ll < 64 || n_tiles_ll > (1 << 28)) return RT_OK; /* a launch this small has no tail worth ordering */
   const int n_tiles = (int)n_tiles_ll;
-  const long long key[6] = {(long long)g.scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
+  const long long key[6] = {(long long)cur->scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
                             -2 - (long long)p->max_depth - ((long long)(p->accel == RT_ACCEL_REFERENCE) << 20)};
-  if (memcmp(key, g.plan_key, sizeof key) != 0) {
-    HIP_TRY(hipDeviceSynchronize()); /* launches in flight on other streams read the list that is about to change */
+  bool fresh = false;
+  Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh) {
     int32_t* d_cost = nullptr;
     HIP_TRY(hipMalloc((void**)&d_cost, sizeof(int32_t) * (size_t)n_tiles));
     std::vector<int32_t> cost((size_t)n_tiles), order((size_t)n_tiles);
@@ -669,7 +685,7 @@ int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const
     hipError_t e = hipMemsetAsync(d_cost, 0, sizeof(int32_t) * (size_t)n_tiles, s);
     if (e == hipSuccess) {
       const unsigned threads = RT_TILE_W * RT_TILE_H;
-      launch_general_cap<true, false>(dim3((unsigned)(((size_t)n_tiles * 4 + threads - 1) / threads)), s, pa, nullptr, d_cost,
+      launch_general_cap<true>(dim3((unsigned)(((size_t)n_tiles * 4 + threads - 1) / threads)), s, pa, nullptr, d_cost,
                                       nullptr, nullptr);
       e = hipGetLastError();
     }
@@ -691,24 +707,16 @@ int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const
       if (block_cost[ba] != block_cost[bb]) return block_cost[ba] > block_cost[bb];
       return ba < bb;
     });
-    if ((size_t)n_tiles > g.tile_list_cap) {
-      if (g.d_tile_list) (void)hipFree(g.d_tile_list);
-      g.d_tile_list = nullptr;
-      g.tile_list_cap = 0;
-      HIP_TRY(hipMalloc((void**)&g.d_tile_list, sizeof(int32_t) * (size_t)n_tiles));
-      g.tile_list_cap = (size_t)n_tiles;
-    }
-    HIP_TRY(hipMemcpyAsync(g.d_tile_list, order.data(), sizeof(int32_t) * (size_t)n_tiles, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
-    memcpy(g.plan_key, key, sizeof key);
+    const int src = store_plan(plan, key, order, s);
+    if (src != RT_OK) return src;
   }
-  g.launch_tile_list = g.d_tile_list;
+  cur->launch_tile_list = plan->d_list;
   return RT_OK;
 }
 
 int check_params(const rt_render_params* p) {
   if (!p) return RT_ERR_INVALID;
-  if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
+  if (!cur->ready || !cur->have_scene) return RT_ERR_NOT_READY;
   if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH) return RT_ERR_TOO_LARGE;
   if (p->spp_grid < 1) return RT_ERR_INVALID;
   if (p->spp_grid > RT_MAX_SPP_GRID) return RT_ERR_TOO_LARGE;
@@ -716,14 +724,14 @@ int check_params(const rt_render_params* p) {
   if (p->n_ranks > 1 && p->band_rows < 1) return RT_ERR_INVALID;
   if (p->accel != RT_ACCEL_AUTO && p->accel != RT_ACCEL_BRUTE && p->accel != RT_ACCEL_BVH && p->accel != RT_ACCEL_REFERENCE)
     return RT_ERR_INVALID;
-  if (p->accel == RT_ACCEL_BVH && g.scene.n_bvh_nodes == 0 && g.scene.n_tris > 0 && !g.bvh_single_leaf)
+  if (p->accel == RT_ACCEL_BVH && cur->scene.n_bvh_nodes == 0 && cur->scene.n_tris > 0 && !cur->bvh_single_leaf)
     return RT_ERR_NOT_READY;
   return RT_OK;
 }
 
 /* enqueue one render on `s`; waits and fills stats only when stats != NULL */
 int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats) {
-  const int W = g.scene.hsize, H = g.scene.vsize;
+  const int W = cur->scene.hsize, H = cur->scene.vsize;
   const int rows = rt_hip_rank_rows(H, p->band_rows, p->n_ranks, p->rank);
   RenderArgs a;
   a.max_depth = p->max_depth;
@@ -732,28 +740,19 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   a.n_ranks = p->n_ranks;
   a.rank = p->rank;
   a.rows = rows;
-  a.ablate = p->reserved;
+  a.ablate = (p->flags >> 8) & 0xff; /* development builds only (RT_ABLATE) */
   for (int i = 0; i < RT_MAX_SPP_GRID; ++i) a.sample_off[i] = (i + 0.5) / a.spp_grid; /* ref_harness / oracle: (i + 0.5) / G */
-  const bool general = g.general || p->accel == RT_ACCEL_REFERENCE;
-  if (general && !g.d_gen_scene) return RT_ERR_TOO_LARGE; /* too many objects for the every-ray-every-object kernel */
-  bool bvh = g.scene.n_bvh_nodes > 0 && g.scene.n_tris > 0;
+  const bool general = cur->general || p->accel == RT_ACCEL_REFERENCE;
+  if (general && !cur->d_gen_scene) return RT_ERR_TOO_LARGE; /* too many objects for the every-ray-every-object kernel */
+  bool bvh = cur->scene.n_bvh_nodes > 0 && cur->scene.n_tris > 0;
   if (p->accel == RT_ACCEL_BRUTE) bvh = false;
-  if (p->accel == RT_ACCEL_AUTO && g.scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
+  if (p->accel == RT_ACCEL_AUTO && cur->scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
   const bool count = p->count_rays != 0 && stats != nullptr;
-  const bool reflect = g.reflective && p->max_depth >= 1;
-  /* A caller that moves from stream to stream has frames in flight side by side; 64 calls in a row on one
-   * stream end that assumption (each change of mind re-plans the tile list once). */
-  if (g.have_last_stream && s != g.last_stream) {
-    g.frames_overlap = true;
-    g.same_stream_calls = 0;
-  } else if (g.frames_overlap && ++g.same_stream_calls >= 64) {
-    g.frames_overlap = false;
-  }
-  g.last_stream = s;
-  g.have_last_stream = true;
+  const bool reflect = cur->reflective && p->max_depth >= 1;
+  const bool overlap = (p->flags & RT_RENDER_FRAMES_OVERLAP) != 0;
   if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
-    if (count) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 6 * sizeof(unsigned long long), s));
+    if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 6 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     int n_blocks = 0;
     if (general) {
@@ -766,28 +765,28 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
       const int prc = plan_general_tiles(p, rows, s, a);
       if (prc != RT_OK) return prc;
     } else {
-      const int prc = plan_tiles(p, rows, bvh, reflect, s, a, n_blocks);
+      const int prc = plan_tiles(p, rows, bvh, reflect, overlap, s, a, n_blocks);
       if (prc != RT_OK) return prc;
     }
     (void)n_tiles;
     dim3 grid((unsigned)n_blocks);
-    if (stats) HIP_TRY(hipEventRecord(g.ev0, s));
-    if (general) launch_general(count, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
-    else launch(count, bvh, reflect, d_canvas != nullptr, grid, s, a, d_rgb, d_canvas);
+    if (stats) HIP_TRY(hipEventRecord(cur->ev0, s));
+    if (general) launch_general(count, grid, s, a, d_rgb, d_canvas);
+    else launch(count, bvh, reflect, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
-    if (stats) HIP_TRY(hipEventRecord(g.ev1, s));
+    if (stats) HIP_TRY(hipEventRecord(cur->ev1, s));
   }
   if (stats) {
     stats->rows_rendered = rows;
     stats->accel_used = general ? RT_ACCEL_REFERENCE : (bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE);
     if (rows > 0) {
-      HIP_TRY(hipEventSynchronize(g.ev1));
+      HIP_TRY(hipEventSynchronize(cur->ev1));
       float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+      HIP_TRY(hipEventElapsedTime(&ms, cur->ev0, cur->ev1));
       stats->kernel_ms = ms;
       if (count) {
         unsigned long long c[6];
-        HIP_TRY(hipMemcpyAsync(c, g.d_counters, sizeof c, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c, cur->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         stats->rays_primary = c[0];
         stats->rays_shadow = c[1];
@@ -816,6 +815,66 @@ struct BuildBuffers {
   void release(void* p) { for (void*& q : owned) if (q == p) q = nullptr; }
 };
 
+/* stream, events, counters and tuning knobs of the context `cur` points at; the caller has made `device` current */
+int create_context(int device) {
+  HIP_TRY(hipStreamCreateWithFlags(&cur->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&cur->ev0));
+  HIP_TRY(hipEventCreate(&cur->ev1));
+  HIP_TRY(hipEventCreate(&cur->tm0));
+  HIP_TRY(hipEventCreate(&cur->tm1));
+  HIP_TRY(hipEventCreateWithFlags(&cur->ppm_ev, hipEventDisableTiming));
+  HIP_TRY(hipMalloc((void**)&cur->d_counters, 8 * sizeof(unsigned long long)));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  cur->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  /* A/B switches for development builds; a caller states what it wants through rt_render_params */
+  if (const char* e = getenv("RT_HIP_CROWDED_FIRST")) cur->crowded_first = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_SPLIT_TILES")) cur->split_tiles = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS")) cur->split_quarters = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_MAX_PER_CU")) cur->split_max_per_cu = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS_REFLECT")) cur->split_quarters_reflect = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) cur->split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
+  if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) cur->split_min_cost = atoi(e);
+  if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
+  if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */
+  if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) cur->light_per_block = v;
+  }
+  if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */
+  cur->device = device;
+  cur->ready = true;
+  return RT_OK;
+}
+
+/* release whatever `c` holds (also a half-made context) and reset it; makes c's device current */
+void destroy_context(Context* c) {
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  Context* const keep = cur;
+  cur = c;
+  free_scene();
+  cur = keep;
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_scene) (void)hipFree(c->d_scene);
+  for (Context::TilePlan& t : c->plans)
+    if (t.d_list) (void)hipFree(t.d_list);
+  if (c->d_rgb) (void)hipFree(c->d_rgb);
+  if (c->d_canvas) (void)hipFree(c->d_canvas);
+  if (c->d_ppm_len) (void)hipFree(c->d_ppm_len);
+  if (c->d_ppm_group) (void)hipFree(c->d_ppm_group);
+  if (c->d_ppm_text) (void)hipFree(c->d_ppm_text);
+  if (c->h_ppm_total) (void)hipHostFree(c->h_ppm_total);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->tm0) (void)hipEventDestroy(c->tm0);
+  if (c->tm1) (void)hipEventDestroy(c->tm1);
+  if (c->ppm_ev) (void)hipEventDestroy(c->ppm_ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  *c = Context{};
+}
+
 }  // namespace
 
 extern "C" {
@@ -826,42 +885,25 @@ int rt_hip_init(int device) {
     snprintf(g_err, sizeof g_err, "no HIP device");
     return RT_ERR_NO_DEVICE;
   }
-  if (device < 0 || device >= n) return RT_ERR_NO_DEVICE;
-  if (g.ready && g.device == device) return RT_OK;
-  if (g.ready) rt_hip_shutdown();
+  if (device < 0 || device >= n || device >= kMaxDevices) return RT_ERR_NO_DEVICE;
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&g.ev0));
-  HIP_TRY(hipEventCreate(&g.ev1));
-  HIP_TRY(hipEventCreate(&g.tm0));
-  HIP_TRY(hipEventCreate(&g.tm1));
-  HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("RT_HIP_CROWDED_FIRST")) g.crowded_first = atoi(e) != 0;
-  if (const char* e = getenv("RT_HIP_SPLIT_TILES")) g.split_tiles = atoi(e);
-  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS")) g.split_quarters = atoi(e);
-  if (const char* e = getenv("RT_HIP_SPLIT_MAX_PER_CU")) g.split_max_per_cu = atoi(e);
-  if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS_REFLECT")) g.split_quarters_reflect = atoi(e);
-  if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) g.split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
-  if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) g.split_min_cost = atoi(e);
-  if (const char* e = getenv("RT_HIP_XCD_TILES")) g.xcd_tiles = atoi(e) != 0 ? 1 : 0;
-  if (const char* e = getenv("RT_HIP_LDS_STACK")) g.lds_stack = atoi(e) != 0; /* tuning knob: 0 = traversal stack in scratch */
-  if (const char* e = getenv("RT_HIP_LDS")) g.use_lds = atoi(e) != 0; /* tuning knob: 0 = read primitives from global memory */
-  if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) { /* tuning knob */
-    const int v = atoi(e);
-    if (v >= 1 && v <= 64) g.light_per_block = v;
-  }
-  if (const char* e = getenv("RT_HIP_TILE_PLAN")) g.tile_plan = atoi(e) != 0; /* tuning knob: 0 = row-major tiles */
-  g.device = device;
-  g.ready = true;
+  cur = &g_ctx[device];
+  if (cur->ready) return RT_OK;
+  const int rc = create_context(device);
+  if (rc != RT_OK) destroy_context(cur);
+  return rc;
+}
+
+int rt_hip_set_device(int device) {
+  if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready) return RT_ERR_NOT_READY;
+  HIP_TRY(hipSetDevice(device));
+  cur = &g_ctx[device];
   return RT_OK;
 }
 
 int rt_hip_upload_scene(const rt_scene* sc) {
   if (!sc) return RT_ERR_INVALID;
-  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!cur->ready) return RT_ERR_NOT_READY;
   if (sc->camera.hsize < 1 || sc->camera.vsize < 1 || sc->n_spheres < 0 || sc->n_tris < 0 || sc->n_materials < 0)
     return RT_ERR_INVALID;
   /* an empty world is legal (every pixel black); anything else needs its materials */
@@ -897,8 +939,8 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   bool use_bvh = sc->n_bvh_nodes > 0 && sc->bvh_nodes && sc->bvh_tri && nt > 0;
   int depth = 0;
   int n_bvh_inner = 0;
-  g.bvh_single_leaf = use_bvh && sc->bvh_nodes[0].right < 0;
-  if (g.bvh_single_leaf) use_bvh = false; /* nothing to walk: the exhaustive loop is the walk */
+  cur->bvh_single_leaf = use_bvh && sc->bvh_nodes[0].right < 0;
+  if (cur->bvh_single_leaf) use_bvh = false; /* nothing to walk: the exhaustive loop is the walk */
   if (use_bvh) {
     depth = bvh_depth(sc->bvh_nodes, sc->n_bvh_nodes, 0, 0);
     if (depth > RT_BVH_STACK) return RT_ERR_TOO_LARGE;
@@ -992,12 +1034,12 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     hsp[i].c = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) - 1.0;          /* tuple_dot - 1.0, :927 */
   }
   int rc;
-  if ((rc = upload(&g.d_tri_primary, htp.data(), sizeof(DevTriPrimary) * (size_t)nt)) != RT_OK) return rc;
-  if ((rc = upload(&g.d_sph_primary, hsp.data(), sizeof(DevSpherePrimary) * (size_t)ns)) != RT_OK) return rc;
-  if ((rc = upload(&g.d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
-  if ((rc = upload(&g.d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
-  if ((rc = upload(&g.d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
-  if ((rc = upload(&g.d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_tri_primary, htp.data(), sizeof(DevTriPrimary) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_sph_primary, hsp.data(), sizeof(DevSpherePrimary) * (size_t)ns)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
   /* device BVH: inner nodes only, each with both children's boxes.  The host boxes get an extra pad of
    * ~500 float ulps of the largest coordinate in play (mesh, camera, light), far more than rounding the ray
    * origin, its reciprocal direction and the slab products to single precision can move a slab distance. */
@@ -1035,10 +1077,10 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       d2.q[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], 0.f);
     }
     n_bvh_inner = n_inner;
-    if ((rc = upload(&g.d_bvh, hb.data(), sizeof(DevBvh2) * (size_t)n_inner)) != RT_OK) return rc;
+    if ((rc = upload(&cur->d_bvh, hb.data(), sizeof(DevBvh2) * (size_t)n_inner)) != RT_OK) return rc;
   }
 
-  DevScene& d = g.scene;
+  DevScene& d = cur->scene;
   d.pixel_size = sc->camera.pixel_size;
   d.half_width = sc->camera.half_width;
   d.half_height = sc->camera.half_height;
@@ -1051,12 +1093,12 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     d.box_lo[c] = nt ? std::nextafterf((float)(blo[c] - pad), -INFINITY) : 0.f;
     d.box_hi[c] = nt ? std::nextafterf((float)(bhi[c] + pad), INFINITY) : 0.f;
   }
-  for (int c = 0; c < 3; ++c) { g.mesh_lo[c] = blo[c] - pad; g.mesh_hi[c] = bhi[c] + pad; }
+  for (int c = 0; c < 3; ++c) { cur->mesh_lo[c] = blo[c] - pad; cur->mesh_hi[c] = bhi[c] + pad; }
   /* where each triangle lands on the image: the tile order of a launch puts crowded tiles first */
-  g.tri_rect.clear();
+  cur->tri_rect.clear();
   double view[16];
   if (nt > 0 && nt <= kMaxTilePlanTris && invert4(sc->camera.inv_view, view)) {
-    g.tri_rect.resize(4 * (size_t)nt);
+    cur->tri_rect.resize(4 * (size_t)nt);
     const double W = sc->camera.hsize, H = sc->camera.vsize;
     for (int k = 0; k < nt; ++k) {
       const DevTri& t = ht[k];
@@ -1072,12 +1114,12 @@ int rt_hip_upload_scene(const rt_scene* sc) {
         x0 = std::fmin(x0, (float)px); x1 = std::fmax(x1, (float)px);
         y0 = std::fmin(y0, (float)py); y1 = std::fmax(y1, (float)py);
       }
-      float* q = &g.tri_rect[4 * (size_t)k];
+      float* q = &cur->tri_rect[4 * (size_t)k];
       q[0] = x0 - 1.f; q[1] = y0 - 1.f; q[2] = x1 + 1.f; q[3] = y1 + 1.f;
     }
   }
-  g.box_pad = pad;
-  g.scene_serial++;
+  cur->box_pad = pad;
+  cur->scene_serial++;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
   memcpy(d.light_int, sc->light.intensity, sizeof d.light_int);
   d.hsize = sc->camera.hsize;
@@ -1086,13 +1128,13 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   d.n_tris = nt;
   d.n_bvh_nodes = use_bvh ? n_bvh_inner : 0;
   d.bvh_depth = depth;
-  g.host_camera = sc->camera;
-  g.reflective = false;
+  cur->host_camera = sc->camera;
+  cur->reflective = false;
   for (int i = 0; i < sc->n_materials; ++i)
-    if (!(std::fabs(sc->materials[i].reflective - 0.0) < RT_EPSILON)) g.reflective = true;
-  if (!g.d_scene) HIP_TRY(hipMalloc((void**)&g.d_scene, sizeof(DevScene)));
-  HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
-  g.have_scene = true;
+    if (!(std::fabs(sc->materials[i].reflective - 0.0) < RT_EPSILON)) cur->reflective = true;
+  if (!cur->d_scene) HIP_TRY(hipMalloc((void**)&cur->d_scene, sizeof(DevScene)));
+  HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
+  cur->have_scene = true;
   /* small worlds also get the general kernel's form, for RT_ACCEL_REFERENCE */
   if (n_prims <= kMaxReferenceObjects) {
     const int rc = upload_general(sc, false);
@@ -1100,7 +1142,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   }
   /* A mesh this large without a tree would be walked exhaustively by every ray (seconds per frame): build one
    * here.  A tree that turns out too deep for the walk leaves the scene as it is. */
-  if (!use_bvh && !g.bvh_single_leaf && nt >= kAutoDeviceBvhTris) {
+  if (!use_bvh && !cur->bvh_single_leaf && nt >= kAutoDeviceBvhTris) {
     const int rc = rt_hip_build_bvh_device(4, nullptr);
     if (rc != RT_OK && rc != RT_ERR_TOO_LARGE) return rc;
   }
@@ -1108,20 +1150,20 @@ int rt_hip_upload_scene(const rt_scene* sc) {
 }
 
 int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
-  if (!g.ready || !g.have_scene) return RT_ERR_NOT_READY;
+  if (!cur->ready || !cur->have_scene) return RT_ERR_NOT_READY;
   if (leaf_size < 1 || leaf_size > 7) return RT_ERR_INVALID;
-  if (g.general) return RT_ERR_UNSUPPORTED; /* worlds of the general kernel walk the reference's list */
-  const int n = g.scene.n_tris;
+  if (cur->general) return RT_ERR_UNSUPPORTED; /* worlds of the general kernel walk the reference's list */
+  const int n = cur->scene.n_tris;
   if (n >= (1 << 27)) return RT_ERR_TOO_LARGE;
   if (info) memset(info, 0, sizeof *info);
   if (n <= leaf_size) { /* nothing to walk: the exhaustive loop is the walk */
-    if (g.d_bvh) (void)hipFree(g.d_bvh);
-    g.d_bvh = nullptr;
-    g.scene.n_bvh_nodes = 0;
-    g.scene.bvh_depth = 0;
-    g.bvh_single_leaf = n > 0;
-    HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
-    g.scene_serial++;
+    if (cur->d_bvh) (void)hipFree(cur->d_bvh);
+    cur->d_bvh = nullptr;
+    cur->scene.n_bvh_nodes = 0;
+    cur->scene.bvh_depth = 0;
+    cur->bvh_single_leaf = n > 0;
+    HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
+    cur->scene_serial++;
     return RT_OK;
   }
   /* what the scene keeps afterwards: one allocation each; everything else: one allocation carved up */
@@ -1134,8 +1176,8 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   if (!b.get(&tris_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
   size_t sort_bytes = 0, scan_bytes = 0;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63, g.stream));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int)ni, g.stream));
+                                             (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63, cur->stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int)ni, cur->stream));
   const size_t space_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes; /* both library calls work in it, in turn */
   size_t arena_bytes = 0;
   auto reserve = [&](size_t bytes) { const size_t at = arena_bytes; arena_bytes += (bytes + 255) & ~(size_t)255; return at; };
@@ -1169,24 +1211,24 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
 
   double scale[3];
   for (int c = 0; c < 3; ++c) {
-    const double extent = g.mesh_hi[c] - g.mesh_lo[c];
+    const double extent = cur->mesh_hi[c] - cur->mesh_lo[c];
     scale[c] = extent > 0.0 ? 2097152.0 / extent : 0.0;
   }
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return RT_ERR_HIP; }
   const dim3 per_tri((unsigned)((nn + LBVH_THREADS - 1) / LBVH_THREADS)), per_node((unsigned)((ni + LBVH_THREADS - 1) / LBVH_THREADS));
-  hipStream_t s = g.stream;
+  hipStream_t s = cur->stream;
   hipError_t e = hipEventRecord(e0, s);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(lbvh_keys_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)g.d_tris, n, g.mesh_lo[0], g.mesh_lo[1],
-                       g.mesh_lo[2], scale[0], scale[1], scale[2], keys, index);
+    hipLaunchKernelGGL(lbvh_keys_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)cur->d_tris, n, cur->mesh_lo[0], cur->mesh_lo[1],
+                       cur->mesh_lo[2], scale[0], scale[1], scale[2], keys, index);
     e = hipcub::DeviceRadixSort::SortPairs(sort_space, sort_bytes, keys, keys_sorted, index, index_sorted, n, 0, 63, s);
   }
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(lbvh_gather_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)g.d_tris,
-                       (const DevTriPrimary*)g.d_tri_primary, (const double*)g.d_normals, (const unsigned*)index_sorted, n,
-                       g.box_pad, tris_out, prim_out, normals_out, leaf_lo, leaf_hi);
+    hipLaunchKernelGGL(lbvh_gather_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)cur->d_tris,
+                       (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const unsigned*)index_sorted, n,
+                       cur->box_pad, tris_out, prim_out, normals_out, leaf_lo, leaf_hi);
     hipLaunchKernelGGL(lbvh_hierarchy_kernel, per_node, dim3(LBVH_THREADS), 0, s, (const unsigned long long*)keys_sorted, n, leaf_size,
                        walked, left, right, range_lo, range_hi, parent_of_node, parent_of_leaf);
     e = hipMemsetAsync(visits, 0, sizeof(unsigned) * ni, s);
@@ -1222,19 +1264,19 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
     return RT_ERR_TOO_LARGE;
   }
   /* hand over: the sorted triangle arrays and the nodes replace the scene's */
-  if (g.d_tris) (void)hipFree(g.d_tris);
-  if (g.d_tri_primary) (void)hipFree(g.d_tri_primary);
-  if (g.d_normals) (void)hipFree(g.d_normals);
-  if (g.d_bvh) (void)hipFree(g.d_bvh);
-  g.d_tris = tris_out; b.release(tris_out);
-  g.d_tri_primary = prim_out; b.release(prim_out);
-  g.d_normals = normals_out; b.release(normals_out);
-  g.d_bvh = nodes; b.release(nodes);
-  g.scene.n_bvh_nodes = n_walked;
-  g.scene.bvh_depth = depth;
-  g.bvh_single_leaf = false;
-  HIP_TRY(hipMemcpy(g.d_scene, &g.scene, sizeof(DevScene), hipMemcpyHostToDevice));
-  g.scene_serial++;
+  if (cur->d_tris) (void)hipFree(cur->d_tris);
+  if (cur->d_tri_primary) (void)hipFree(cur->d_tri_primary);
+  if (cur->d_normals) (void)hipFree(cur->d_normals);
+  if (cur->d_bvh) (void)hipFree(cur->d_bvh);
+  cur->d_tris = tris_out; b.release(tris_out);
+  cur->d_tri_primary = prim_out; b.release(prim_out);
+  cur->d_normals = normals_out; b.release(normals_out);
+  cur->d_bvh = nodes; b.release(nodes);
+  cur->scene.n_bvh_nodes = n_walked;
+  cur->scene.bvh_depth = depth;
+  cur->bvh_single_leaf = false;
+  HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
+  cur->scene_serial++;
   if (info) { info->n_nodes = n_walked; info->depth = depth; info->build_ms = ms; }
   return RT_OK;
 }
@@ -1246,7 +1288,7 @@ size_t rt_hip_ppm_capacity(int width, int height) {
 
 int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void* text_device, size_t capacity,
                              size_t* bytes_out, void* stream) {
-  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!cur->ready) return RT_ERR_NOT_READY;
   if (!rgb_device || !text_device || width < 0 || height < 0) return RT_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(rgb_device) & 3u) != 0 || (reinterpret_cast<uintptr_t>(text_device) & 15u) != 0)
     return RT_ERR_INVALID;
@@ -1255,79 +1297,85 @@ int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void
   const long long n_chunks_ll = (n_px + PPM_CHUNK - 1) / PPM_CHUNK;
   if (n_chunks_ll > (1ll << 30)) return RT_ERR_TOO_LARGE;
   const int n_chunks = (int)n_chunks_ll;
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
   PpmHeader hd;
   memset(&hd, 0, sizeof hd);
   hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
-  if (!g.h_ppm_total) {
-    HIP_TRY(hipHostMalloc((void**)&g.h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_TRY(hipHostGetDevicePointer((void**)&g.d_ppm_total_host, g.h_ppm_total, 0));
+  if (!cur->h_ppm_total) {
+    HIP_TRY(hipHostMalloc((void**)&cur->h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&cur->d_ppm_total_host, cur->h_ppm_total, 0));
   }
   /* groups: about a thousand of them keep both the length pass parallel and a chunk's sum over groups short */
   int per_group = n_chunks / 1024;
   per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
   const int n_groups = (n_chunks + per_group - 1) / per_group;
-  if ((size_t)n_chunks + 1 > g.ppm_chunks_cap) {
-    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream));
-    if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
-    if (g.d_ppm_group) (void)hipFree(g.d_ppm_group);
-    g.d_ppm_len = nullptr;
-    g.d_ppm_group = nullptr;
-    g.ppm_chunks_cap = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
-    HIP_TRY(hipMalloc((void**)&g.d_ppm_group, sizeof(unsigned) * ((size_t)n_chunks + 1)));
-    g.ppm_chunks_cap = (size_t)n_chunks + 1;
+  if ((size_t)n_chunks + 1 > cur->ppm_chunks_cap) {
+    if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream));
+    if (cur->d_ppm_len) (void)hipFree(cur->d_ppm_len);
+    if (cur->d_ppm_group) (void)hipFree(cur->d_ppm_group);
+    cur->d_ppm_len = nullptr;
+    cur->d_ppm_group = nullptr;
+    cur->ppm_chunks_cap = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
+    HIP_TRY(hipMalloc((void**)&cur->d_ppm_group, sizeof(unsigned) * ((size_t)n_chunks + 1)));
+    cur->ppm_chunks_cap = (size_t)n_chunks + 1;
+  }
+  /* every call shares the length arrays and the pinned length word: a call on another stream than the last one
+   * starts after that one has finished */
+  if (cur->ppm_pending && cur->ppm_stream != s) {
+    HIP_TRY(hipEventRecord(cur->ppm_ev, cur->ppm_stream));
+    HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
   }
   if (n_chunks > 0) {
     hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, n_chunks, per_group, g.d_ppm_len, g.d_ppm_group);
+                       (const unsigned char*)rgb_device, n_px, n_chunks, per_group, cur->d_ppm_len, cur->d_ppm_group);
     hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, (const unsigned*)g.d_ppm_len, (const unsigned*)g.d_ppm_group,
-                       per_group, hd, (unsigned char*)text_device, g.d_ppm_total_host);
+                       (const unsigned char*)rgb_device, n_px, (const unsigned*)cur->d_ppm_len, (const unsigned*)cur->d_ppm_group,
+                       per_group, hd, (unsigned char*)text_device, cur->d_ppm_total_host);
   } else {
-    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream)); /* nobody else is writing the length word */
+    if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream)); /* nobody else is writing the length word */
     HIP_TRY(hipMemcpyAsync(text_device, hd.text, (size_t)hd.len, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s)); /* hd lives on this stack frame */
-    *g.h_ppm_total = (unsigned long long)hd.len;
+    *cur->h_ppm_total = (unsigned long long)hd.len;
   }
   HIP_TRY(hipGetLastError());
-  g.ppm_stream = s; /* the scan kernel has put the length into *h_ppm_total once the stream has drained */
-  g.ppm_pending = true;
+  cur->ppm_stream = s; /* the scan kernel has put the length into *h_ppm_total once the stream has drained */
+  cur->ppm_pending = true;
   if (bytes_out) return rt_hip_ppm_last_length(bytes_out);
   return RT_OK;
 }
 
 int rt_hip_ppm_last_length(size_t* bytes_out) {
-  if (!g.ready || !g.h_ppm_total) return RT_ERR_NOT_READY;
+  if (!cur->ready || !cur->h_ppm_total) return RT_ERR_NOT_READY;
   if (!bytes_out) return RT_ERR_INVALID;
-  if (g.ppm_pending) {
-    HIP_TRY(hipStreamSynchronize(g.ppm_stream));
-    g.ppm_pending = false;
+  if (cur->ppm_pending) {
+    HIP_TRY(hipStreamSynchronize(cur->ppm_stream));
+    cur->ppm_pending = false;
   }
-  *bytes_out = (size_t)*g.h_ppm_total;
+  *bytes_out = (size_t)*cur->h_ppm_total;
   return RT_OK;
 }
 
 int rt_hip_format_ppm(const void* rgb_device, int width, int height, char* text_host, size_t capacity,
                       size_t* bytes_out) {
-  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!cur->ready) return RT_ERR_NOT_READY;
   if (!text_host && capacity > 0) return RT_ERR_INVALID;
   const size_t need = rt_hip_ppm_capacity(width, height);
-  if (need > g.d_ppm_text_bytes) {
-    if (g.ppm_pending) HIP_TRY(hipStreamSynchronize(g.ppm_stream));
-    if (g.d_ppm_text) (void)hipFree(g.d_ppm_text);
-    g.d_ppm_text = nullptr;
-    g.d_ppm_text_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_ppm_text, need));
-    g.d_ppm_text_bytes = need;
+  if (need > cur->d_ppm_text_bytes) {
+    if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream));
+    if (cur->d_ppm_text) (void)hipFree(cur->d_ppm_text);
+    cur->d_ppm_text = nullptr;
+    cur->d_ppm_text_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_ppm_text, need));
+    cur->d_ppm_text_bytes = need;
   }
   size_t len = 0;
-  const int rc = rt_hip_format_ppm_device(rgb_device, width, height, g.d_ppm_text, g.d_ppm_text_bytes, &len, g.stream);
+  const int rc = rt_hip_format_ppm_device(rgb_device, width, height, cur->d_ppm_text, cur->d_ppm_text_bytes, &len, cur->stream);
   if (rc != RT_OK) return rc;
   if (bytes_out) *bytes_out = len;
   if (len > capacity) return RT_ERR_TOO_LARGE;
-  if (len) HIP_TRY(hipMemcpyAsync(text_host, g.d_ppm_text, len, hipMemcpyDeviceToHost, g.stream));
-  HIP_TRY(hipStreamSynchronize(g.stream));
+  if (len) HIP_TRY(hipMemcpyAsync(text_host, cur->d_ppm_text, len, hipMemcpyDeviceToHost, cur->stream));
+  HIP_TRY(hipStreamSynchronize(cur->stream));
   return RT_OK;
 }
 
@@ -1335,17 +1383,17 @@ int rt_hip_render_ppm(const rt_render_params* p, char* text_host, size_t capacit
   int rc = check_params(p);
   if (rc != RT_OK) return rc;
   if (p->n_ranks != 1) return RT_ERR_INVALID; /* the file is one whole frame */
-  const size_t bytes = (size_t)g.scene.vsize * g.scene.hsize * 3;
-  if (bytes > g.d_rgb_bytes) {
-    if (g.d_rgb) (void)hipFree(g.d_rgb);
-    g.d_rgb = nullptr;
-    g.d_rgb_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_rgb, bytes ? bytes : 16));
-    g.d_rgb_bytes = bytes;
+  const size_t bytes = (size_t)cur->scene.vsize * cur->scene.hsize * 3;
+  if (bytes > cur->d_rgb_bytes) {
+    if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+    cur->d_rgb = nullptr;
+    cur->d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes ? bytes : 16));
+    cur->d_rgb_bytes = bytes;
   }
-  rc = render_common(p, g.d_rgb, nullptr, g.stream, stats);
+  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats);
   if (rc != RT_OK) return rc;
-  return rt_hip_format_ppm(g.d_rgb, g.scene.hsize, g.scene.vsize, text_host, capacity, bytes_out);
+  return rt_hip_format_ppm(cur->d_rgb, cur->scene.hsize, cur->scene.vsize, text_host, capacity, bytes_out);
 }
 
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank) {
@@ -1372,7 +1420,7 @@ int rt_hip_render_device(const rt_render_params* p, void* rgb_out_device, void* 
   int rc = check_params(p);
   if (rc != RT_OK) return rc;
   if (!rgb_out_device) return RT_ERR_INVALID;
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
   return render_common(p, (unsigned char*)rgb_out_device, nullptr, s, stats);
 }
 
@@ -1380,19 +1428,19 @@ int rt_hip_render(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) 
   int rc = check_params(p);
   if (rc != RT_OK) return rc;
   if (!rgb_out) return RT_ERR_INVALID;
-  const int rows = rt_hip_rank_rows(g.scene.vsize, p->band_rows, p->n_ranks, p->rank);
-  const size_t bytes = (size_t)rows * g.scene.hsize * 3;
-  if (bytes > g.d_rgb_bytes) {
-    if (g.d_rgb) (void)hipFree(g.d_rgb);
-    g.d_rgb = nullptr;
-    g.d_rgb_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_rgb, bytes));
-    g.d_rgb_bytes = bytes;
+  const int rows = rt_hip_rank_rows(cur->scene.vsize, p->band_rows, p->n_ranks, p->rank);
+  const size_t bytes = (size_t)rows * cur->scene.hsize * 3;
+  if (bytes > cur->d_rgb_bytes) {
+    if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+    cur->d_rgb = nullptr;
+    cur->d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes));
+    cur->d_rgb_bytes = bytes;
   }
-  rc = render_common(p, g.d_rgb, nullptr, g.stream, stats);
+  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats);
   if (rc != RT_OK) return rc;
-  if (bytes) HIP_TRY(hipMemcpyAsync(rgb_out, g.d_rgb, bytes, hipMemcpyDeviceToHost, g.stream));
-  HIP_TRY(hipStreamSynchronize(g.stream));
+  if (bytes) HIP_TRY(hipMemcpyAsync(rgb_out, cur->d_rgb, bytes, hipMemcpyDeviceToHost, cur->stream));
+  HIP_TRY(hipStreamSynchronize(cur->stream));
   return RT_OK;
 }
 
@@ -1400,60 +1448,44 @@ int rt_hip_render_f64(const rt_render_params* p, double* canvas_out, rt_stats* s
   int rc = check_params(p);
   if (rc != RT_OK) return rc;
   if (!canvas_out) return RT_ERR_INVALID;
-  const int rows = rt_hip_rank_rows(g.scene.vsize, p->band_rows, p->n_ranks, p->rank);
-  const size_t bytes = (size_t)rows * g.scene.hsize * 3 * sizeof(double);
-  if (bytes > g.d_canvas_bytes) {
-    if (g.d_canvas) (void)hipFree(g.d_canvas);
-    g.d_canvas = nullptr;
-    g.d_canvas_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_canvas, bytes));
-    g.d_canvas_bytes = bytes;
+  const int rows = rt_hip_rank_rows(cur->scene.vsize, p->band_rows, p->n_ranks, p->rank);
+  const size_t bytes = (size_t)rows * cur->scene.hsize * 3 * sizeof(double);
+  if (bytes > cur->d_canvas_bytes) {
+    if (cur->d_canvas) (void)hipFree(cur->d_canvas);
+    cur->d_canvas = nullptr;
+    cur->d_canvas_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_canvas, bytes));
+    cur->d_canvas_bytes = bytes;
   }
-  rc = render_common(p, nullptr, g.d_canvas, g.stream, stats);
+  rc = render_common(p, nullptr, cur->d_canvas, cur->stream, stats);
   if (rc != RT_OK) return rc;
-  if (bytes) HIP_TRY(hipMemcpyAsync(canvas_out, g.d_canvas, bytes, hipMemcpyDeviceToHost, g.stream));
-  HIP_TRY(hipStreamSynchronize(g.stream));
+  if (bytes) HIP_TRY(hipMemcpyAsync(canvas_out, cur->d_canvas, bytes, hipMemcpyDeviceToHost, cur->stream));
+  HIP_TRY(hipStreamSynchronize(cur->stream));
   return RT_OK;
 }
 
 int rt_hip_event_record(int which, void* stream) {
-  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!cur->ready) return RT_ERR_NOT_READY;
   if (which != 0 && which != 1) return RT_ERR_INVALID;
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
-  HIP_TRY(hipEventRecord(which == 0 ? g.tm0 : g.tm1, s));
+  hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
+  HIP_TRY(hipEventRecord(which == 0 ? cur->tm0 : cur->tm1, s));
   return RT_OK;
 }
 
 int rt_hip_event_elapsed_ms(double* ms_out) {
-  if (!g.ready) return RT_ERR_NOT_READY;
+  if (!cur->ready) return RT_ERR_NOT_READY;
   if (!ms_out) return RT_ERR_INVALID;
-  HIP_TRY(hipEventSynchronize(g.tm1));
+  HIP_TRY(hipEventSynchronize(cur->tm1));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, g.tm0, g.tm1));
+  HIP_TRY(hipEventElapsedTime(&ms, cur->tm0, cur->tm1));
   *ms_out = ms;
   return RT_OK;
 }
 
 void rt_hip_shutdown(void) {
-  if (!g.ready) return;
-  (void)hipSetDevice(g.device);
-  (void)hipStreamSynchronize(g.stream);
-  free_scene();
-  if (g.d_counters) (void)hipFree(g.d_counters);
-  if (g.d_scene) (void)hipFree(g.d_scene);
-  if (g.d_tile_list) (void)hipFree(g.d_tile_list);
-  if (g.d_rgb) (void)hipFree(g.d_rgb);
-  if (g.d_canvas) (void)hipFree(g.d_canvas);
-  if (g.d_ppm_len) (void)hipFree(g.d_ppm_len);
-  if (g.d_ppm_group) (void)hipFree(g.d_ppm_group);
-  if (g.d_ppm_text) (void)hipFree(g.d_ppm_text);
-  if (g.h_ppm_total) (void)hipHostFree(g.h_ppm_total);
-  if (g.ev0) (void)hipEventDestroy(g.ev0);
-  if (g.ev1) (void)hipEventDestroy(g.ev1);
-  if (g.tm0) (void)hipEventDestroy(g.tm0);
-  if (g.tm1) (void)hipEventDestroy(g.tm1);
-  if (g.stream) (void)hipStreamDestroy(g.stream);
-  g = Context{};
+  for (int d = 0; d < kMaxDevices; ++d)
+    if (g_ctx[d].ready || g_ctx[d].stream) destroy_context(&g_ctx[d]);
+  cur = &g_ctx[0];
 }
 
 const char* rt_hip_strerror(int status) {

@@ -26,8 +26,12 @@ def _check(rc, what):
 
 
 def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0,
-                reserved=0):
-    return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, reserved)
+                flags=0, frames_overlap=False):
+    """rt_render_params; frames_overlap=True states that the caller keeps several frames in flight on different
+    streams (RT_RENDER_FRAMES_OVERLAP)."""
+    if frames_overlap:
+        flags |= _ffi.RT_RENDER_FRAMES_OVERLAP
+    return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, flags)
 
 
 class HipRenderer:

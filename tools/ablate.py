@@ -1,5 +1,5 @@
 """Where does the frame time go?  Back-to-back launches (the clock stays up), HIP events around the batch.
-The `reserved` field of rt_render_params selects a timing-only cut of the kernel (development aid)."""
+Bits 8-15 of the `flags` field of rt_render_params select a timing-only cut of the kernel (development aid)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -25,7 +25,7 @@ for scene in scenes:
                 continue
             if an == "bvh" and scene == "spheres":
                 continue
-            p = R.make_params(reserved=mode, accel=accel)
+            p = R.make_params(flags=mode << 8, accel=accel)
             res = []
             for rep in range(3):
                 for _ in range(20):

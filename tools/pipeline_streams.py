@@ -10,8 +10,8 @@ K = 400
 for scene, accel in (("cube", R._ffi.RT_ACCEL_AUTO), ("spheres", R._ffi.RT_ACCEL_AUTO), ("lighthouse", R._ffi.RT_ACCEL_BVH),
                      ("lighthouse_refl", R._ffi.RT_ACCEL_BVH)):
     r.upload(R.stock_scene(scene.replace("_refl", ""), 1920, 1080, 0.3 if scene.endswith("_refl") else 0.0))
-    p = R.make_params(accel=accel)
     for S in (1, 2, 3, 4, 8):
+        p = R.make_params(accel=accel, frames_overlap=S > 1)
         streams = [torch.cuda.Stream() for _ in range(S)]
         bufs = [torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda:0") for _ in range(S)]
         torch.cuda.synchronize()
