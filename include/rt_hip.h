@@ -285,6 +285,20 @@ int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void
                              size_t* bytes_out, void* stream);
 int rt_hip_ppm_last_length(size_t* bytes_out);
 
+/* rt_hip_format_ppm_device for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
+ * no counterpart in the reference.  The call allocates nothing and frees
+ * nothing: the per-chunk text lengths live in a fixed array in the library's
+ * device image (256 KiB per GPU, held until the process ends), which limits
+ * the image to 67,108,864 pixels (RT_ERR_TOO_LARGE beyond).  The length of the
+ * text is stored to *length_device (device memory, 8-byte aligned) by the
+ * kernel; the call never waits.  Same bytes as rt_hip_format_ppm_device.
+ * All calls on one GPU share the array: calls on different streams are
+ * ordered one after the other by the library; calls from different host
+ * threads at once would race. */
+int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int height, void* text_device,
+                                     size_t capacity, unsigned long long* length_device, void* stream);
+
 /* The same into host memory: formats into a library-owned device buffer and
  * copies the text (not the 13-bytes-per-pixel bound) to text_host.
  * RT_ERR_TOO_LARGE with *bytes_out = needed size if capacity is too small. */

@@ -231,6 +231,8 @@ def hip_lib():
         L.rt_hip_format_ppm_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                                C.POINTER(C.c_size_t), C.c_void_p]
         L.rt_hip_ppm_last_length.argtypes = [C.POINTER(C.c_size_t)]
+        L.rt_hip_format_ppm_device_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                       C.c_void_p]
         L.rt_hip_format_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_hip_render_ppm.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                         C.POINTER(Stats)]
@@ -253,6 +255,7 @@ HIP_EXPORTS = [
     "rt_hip_ppm_capacity",
     "rt_hip_format_ppm_device",
     "rt_hip_ppm_last_length",
+    "rt_hip_format_ppm_device_noalloc",
     "rt_hip_format_ppm",
     "rt_hip_render_ppm",
     "rt_hip_rank_rows",

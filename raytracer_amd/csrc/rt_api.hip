@@ -22,6 +22,12 @@
 #include "rt_ppm.hip.inc"
 #include "rt_lbvh.hip.inc"
 
+/* Scratch of rt_hip_format_ppm_device_noalloc: the text length of every chunk of PPM_CHUNK pixels, then of every
+ * group of chunks.  One copy per GPU, held until the process ends (256 KiB); its address on a device comes from
+ * hipGetSymbolAddress with that device current (create_context), never from the name. */
+constexpr int kNoAllocMaxChunks = 32768; /* x PPM_CHUNK pixels = 67,108,864 pixels, e.g. 8192 x 8192 */
+static __device__ __align__(256) unsigned ppm_scratch[2 * (kNoAllocMaxChunks + 1)];
+
 namespace {
 
 struct Context {
@@ -91,6 +97,9 @@ struct Context {
   hipStream_t ppm_stream = nullptr;          /* stream of the last formatting call */
   bool ppm_pending = false;
   hipEvent_t ppm_ev = nullptr;               /* orders formatting calls on different streams: they share the arrays above */
+  unsigned* ppm_scratch_ptr = nullptr;       /* this device's copy of ppm_scratch */
+  hipStream_t noalloc_stream = nullptr;      /* stream of the last rt_hip_format_ppm_device_noalloc call */
+  bool noalloc_pending = false;
 };
 
 /* One context per HIP device of this process; `cur` is the one the entry points act on (rt_hip_init and
@@ -824,6 +833,7 @@ int create_context(int device) {
   HIP_TRY(hipEventCreate(&cur->tm1));
   HIP_TRY(hipEventCreateWithFlags(&cur->ppm_ev, hipEventDisableTiming));
   HIP_TRY(hipMalloc((void**)&cur->d_counters, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipGetSymbolAddress((void**)&cur->ppm_scratch_ptr, HIP_SYMBOL(ppm_scratch)));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   cur->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1353,6 +1363,50 @@ int rt_hip_ppm_last_length(size_t* bytes_out) {
     cur->ppm_pending = false;
   }
   *bytes_out = (size_t)*cur->h_ppm_total;
+  return RT_OK;
+}
+
+int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int height, void* text_device, size_t capacity,
+                                     unsigned long long* length_device, void* stream) {
+  if (!cur->ready || !cur->ppm_scratch_ptr) return RT_ERR_NOT_READY;
+  if (!rgb_device || !text_device || !length_device || width < 0 || height < 0) return RT_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(rgb_device) & 3u) != 0 || (reinterpret_cast<uintptr_t>(text_device) & 15u) != 0 ||
+      (reinterpret_cast<uintptr_t>(length_device) & 7u) != 0)
+    return RT_ERR_INVALID;
+  if (capacity < rt_hip_ppm_capacity(width, height)) return RT_ERR_TOO_LARGE;
+  const long long n_px = (long long)width * height;
+  const long long n_chunks_ll = (n_px + PPM_CHUNK - 1) / PPM_CHUNK;
+  if (n_chunks_ll > kNoAllocMaxChunks) {
+    snprintf(g_err, sizeof g_err, "rt_hip_format_ppm_device_noalloc: %lld pixels; the fixed scratch holds %lld", n_px,
+             (long long)kNoAllocMaxChunks * PPM_CHUNK);
+    return RT_ERR_TOO_LARGE;
+  }
+  const int n_chunks = (int)n_chunks_ll;
+  hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
+  PpmHeader hd;
+  memset(&hd, 0, sizeof hd);
+  hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
+  int per_group = n_chunks / 1024;
+  per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
+  const int n_groups = (n_chunks + per_group - 1) / per_group;
+  unsigned* const chunk_len = cur->ppm_scratch_ptr;
+  unsigned* const group_len = cur->ppm_scratch_ptr + (kNoAllocMaxChunks + 1);
+  /* the scratch is one per GPU: a call on another stream than the last one starts after that one has finished.
+   * Nothing in it has to start at zero: the length pass writes every entry the write pass reads. */
+  if (cur->noalloc_pending && cur->noalloc_stream != s) {
+    HIP_TRY(hipEventRecord(cur->ppm_ev, cur->noalloc_stream));
+    HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
+  }
+  if (n_chunks > 0)
+    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s, (const unsigned char*)rgb_device, n_px,
+                       n_chunks, per_group, chunk_len, group_len);
+  /* an empty image: one workgroup that finds no pixels writes the header and the length */
+  hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)(n_chunks > 0 ? n_chunks : 1)), dim3(PPM_THREADS), 0, s,
+                     (const unsigned char*)rgb_device, n_px, (const unsigned*)chunk_len, (const unsigned*)group_len, per_group, hd,
+                     (unsigned char*)text_device, length_device);
+  HIP_TRY(hipGetLastError());
+  cur->noalloc_stream = s;
+  cur->noalloc_pending = true;
   return RT_OK;
 }
 

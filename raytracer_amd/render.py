@@ -102,6 +102,12 @@ class HipRenderer:
                "rt_hip_format_ppm_device")
         return int(n.value) if wait else None
 
+    def format_ppm_device_noalloc(self, rgb_ptr, width, height, text_ptr, capacity, length_ptr, stream=None):
+        """The allocation-free variant: the text length goes to the 8-byte device word at length_ptr; never waits."""
+        _check(self._L.rt_hip_format_ppm_device_noalloc(C.c_void_p(rgb_ptr), width, height, C.c_void_p(text_ptr), capacity,
+                                                        C.c_void_p(length_ptr), C.c_void_p(stream or 0)),
+               "rt_hip_format_ppm_device_noalloc")
+
     def ppm_last_length(self):
         n = C.c_size_t(0)
         _check(self._L.rt_hip_ppm_last_length(C.byref(n)), "rt_hip_ppm_last_length")
