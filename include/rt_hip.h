@@ -212,6 +212,11 @@ typedef struct rt_stats {
   double kernel_ms;         /* hipEvent time of the trace kernel, this call      */
   int32_t rows_rendered;    /* rows this rank produced                           */
   int32_t accel_used;       /* RT_ACCEL_BRUTE, RT_ACCEL_BVH or RT_ACCEL_REFERENCE */
+  /* Every ray-primitive test starts in single precision; a primitive the ray cannot be shown to miss goes on
+   * to the double-precision routine that follows intersect_triangle / the sphere branch statement by statement
+   * (RayTracer.c:943-966, 923-940).  How many did: */
+  uint64_t tri_exact;       /* of the triangle tests in prim_tests                */
+  uint64_t sphere_exact;    /* of sphere_tests                                    */
 } rt_stats;
 
 /* Create the context of HIP device `device` (stream, events) if it does not

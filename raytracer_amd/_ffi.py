@@ -140,6 +140,8 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double),
         ("rows_rendered", C.c_int32),
         ("accel_used", C.c_int32),
+        ("tri_exact", C.c_uint64),
+        ("sphere_exact", C.c_uint64),
     ]
 
     @property

@@ -54,6 +54,9 @@ struct Context {
   void* d_normals = nullptr;
   void* d_materials = nullptr;
   void* d_bvh = nullptr;
+  void* d_trif = nullptr;  /* single-precision forms of the triangles (same order as d_tris) and spheres */
+  void* d_sphf = nullptr;
+  double filter_radius = 0.0; /* every ray origin and vertex lies within this distance of the world origin */
   DevScene* d_scene = nullptr; /* device copy of `scene` */
   double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
   double box_pad = 0.0; /* what every single-precision box is grown by */
@@ -138,7 +141,10 @@ void free_scene() {
   if (cur->d_bvh) (void)hipFree(cur->d_bvh);
   if (cur->d_tri_primary) (void)hipFree(cur->d_tri_primary);
   if (cur->d_sph_primary) (void)hipFree(cur->d_sph_primary);
+  if (cur->d_trif) (void)hipFree(cur->d_trif);
+  if (cur->d_sphf) (void)hipFree(cur->d_sphf);
   cur->d_spheres = cur->d_tris = cur->d_normals = cur->d_materials = cur->d_bvh = cur->d_tri_primary = cur->d_sph_primary = nullptr;
+  cur->d_trif = cur->d_sphf = nullptr;
   cur->have_scene = false;
 }
 
@@ -147,6 +153,30 @@ int upload(void** dst, const void* src, size_t bytes) {
   HIP_TRY(hipMalloc(dst, bytes));
   if (src) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   return RT_OK;
+}
+
+/* The single-precision form of a sphere.  inv: rows 0..2 of inverse(transform); origin: the camera origin;
+ * radius as for rt_make_trif.  The filter compares |o' x d'|^2 with |d'|^2.  With eps = 2^-24, Mn = the Frobenius norm
+ * of the linear part of inv, tn = |translation|, Omax = Mn radius + tn >= |o'|, |d| = 1:
+ *   |o'_f - o'| <= 6 eps Omax, |d'_f - d'| <= 5 eps Mn (four resp. three fused products of once-rounded values),
+ *   |(o' x d')_f - o' x d'| <= 6 eps Omax Mn + 5 eps Omax Mn + 7 eps Omax Mn = 18 eps Omax Mn =: Ec.
+ * |c| >= |c_f| - Ec and |d'| <= |d'_f| + 5 eps Mn, so |c_f|^2 > |d'_f|^2 + 2 Mn E + E^2 with
+ * E = 24 eps max(Omax, 1) max(Mn, 1) >= Ec + 5 eps Mn proves |c| > |d'|; the kernel adds a relative 1e-5 for the
+ * rounding of the two squared norms and of the reference's own discriminant. */
+void make_spheref(const double* inv, const double* origin, double radius, DevSphereF* out) {
+  double mn2 = 0.0, tn2 = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) mn2 += inv[4 * r + c] * inv[4 * r + c];
+    tn2 += inv[4 * r + 3] * inv[4 * r + 3];
+  }
+  const double mn = std::sqrt(mn2), tn = std::sqrt(tn2);
+  const double omax = std::fmax(mn * radius + tn, 1.0);
+  const double e = 24.0 * 5.9604644775390625e-8 * omax * std::fmax(mn, 1.0);
+  const double k = (2.0 * mn * e + e * e) * 1.0001 + 1e-30;
+  for (int i = 0; i < 12; ++i) out->inv[i] = (float)inv[i];
+  for (int r = 0; r < 3; ++r)
+    out->po[r] = (float)(((origin[0] * inv[4 * r] + origin[1] * inv[4 * r + 1]) + origin[2] * inv[4 * r + 2]) + inv[4 * r + 3]);
+  out->k = (omax * mn < 1e15 && k < 1e30) ? (float)k : INFINITY; /* NaN compares false: infinite */
 }
 
 int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
@@ -159,7 +189,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
-constexpr int kMaxLdsTris = 256;      /* 256 * (80 + 64) B = 36 KiB */
+constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision forms: four workgroups still fit a CU */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
@@ -171,7 +201,8 @@ void launch_one(size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsig
   hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, STAGE, KIND>), grid, dim3(RT_TILE_W * RT_TILE_H), lds, s, cur->d_scene,
                      (const DevSphere*)cur->d_spheres, (const DevSpherePrimary*)cur->d_sph_primary, (const DevTri*)cur->d_tris,
                      (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const rt_material*)cur->d_materials,
-                     (const DevBvh2*)cur->d_bvh, a, cur->launch_tile_list, rgb, canvas, cur->d_counters);
+                     (const DevBvh2*)cur->d_bvh, (const DevTriF*)cur->d_trif, (const DevSphereF*)cur->d_sphf, a,
+                     cur->launch_tile_list, rgb, canvas, cur->d_counters);
 }
 /* kernels specialised for the primitive kinds the scene holds (KIND 1: spheres only, 2: triangles only, 0: both) */
 template <bool BVH, bool REFLECT, int STAGE>
@@ -208,7 +239,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
   if (cur->use_lds) {
     if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
       stage = 1;
-      lds = (size_t)cur->scene.n_tris * (sizeof(DevTri) + sizeof(DevTriPrimary));
+      lds = (size_t)cur->scene.n_tris * sizeof(DevTriF);
     } else if (bvh && cur->lds_stack && cur->scene.bvh_depth >= 1) {
       /* the traversal stacks, and in front of them the inner nodes if both fit while two workgroups still share
        * a CU's 160 KiB (the walk's register budget allows no more than two anyway) */
@@ -761,7 +792,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   const bool overlap = (p->flags & RT_RENDER_FRAMES_OVERLAP) != 0;
   if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
-    if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 6 * sizeof(unsigned long long), s));
+    if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 8 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     int n_blocks = 0;
     if (general) {
@@ -794,7 +825,7 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
       HIP_TRY(hipEventElapsedTime(&ms, cur->ev0, cur->ev1));
       stats->kernel_ms = ms;
       if (count) {
-        unsigned long long c[6];
+        unsigned long long c[8];
         HIP_TRY(hipMemcpyAsync(c, cur->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         stats->rays_primary = c[0];
@@ -803,6 +834,8 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
         stats->prim_tests = c[3];
         stats->node_tests = c[4];
         stats->sphere_tests = c[5];
+        stats->tri_exact = c[6];
+        stats->sphere_exact = c[7];
       }
     }
   }
@@ -1035,6 +1068,19 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       if (std::isfinite(reach) && reach > amax) amax = reach;
     }
   }
+  /* The single-precision first tests need a radius that holds every vertex and every ray origin (camera, points on
+   * triangles and spheres): sqrt(3) x the largest coordinate.  A sphere whose extent is unknown leaves none. */
+  bool radius_known = true;
+  for (int i = 0; i < ns; ++i) {
+    double fwd[16];
+    if (!invert4(sc->sph_inv + 16 * (size_t)i, fwd)) radius_known = false;
+  }
+  const double radius = radius_known ? 1.7320508075688772 * amax * 1.0001 + 1e-5 : INFINITY;
+  cur->filter_radius = radius;
+  std::vector<DevTriF> htf((size_t)(nt > 0 ? nt : 1));
+  for (int k = 0; k < nt; ++k) rt_make_trif(ht[k], radius, &htf[k]);
+  std::vector<DevSphereF> hsf((size_t)(ns > 0 ? ns : 1));
+  for (int i = 0; i < ns; ++i) make_spheref(hs[i].inv, org, radius, &hsf[i]);
   std::vector<DevSpherePrimary> hsp((size_t)(ns > 0 ? ns : 1));
   for (int i = 0; i < ns; ++i) {
     const double* m = hs[i].inv;
@@ -1048,6 +1094,8 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if ((rc = upload(&cur->d_sph_primary, hsp.data(), sizeof(DevSpherePrimary) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_trif, htf.data(), sizeof(DevTriF) * (size_t)nt)) != RT_OK) return rc;
+  if ((rc = upload(&cur->d_sphf, hsf.data(), sizeof(DevSphereF) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
   /* device BVH: inner nodes only, each with both children's boxes.  The host boxes get an extra pad of
@@ -1179,11 +1227,12 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   /* what the scene keeps afterwards: one allocation each; everything else: one allocation carved up */
   BuildBuffers b;
   DevTri* tris_out;
+  DevTriF* trif_out;
   DevTriPrimary* prim_out;
   double* normals_out;
   DevBvh2* nodes;
   const size_t nn = (size_t)n, ni = nn - 1;
-  if (!b.get(&tris_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
+  if (!b.get(&tris_out, nn) || !b.get(&trif_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
   size_t sort_bytes = 0, scan_bytes = 0;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63, cur->stream));
@@ -1238,7 +1287,7 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   if (e == hipSuccess) {
     hipLaunchKernelGGL(lbvh_gather_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)cur->d_tris,
                        (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const unsigned*)index_sorted, n,
-                       cur->box_pad, tris_out, prim_out, normals_out, leaf_lo, leaf_hi);
+                       cur->box_pad, cur->filter_radius, trif_out, tris_out, prim_out, normals_out, leaf_lo, leaf_hi);
     hipLaunchKernelGGL(lbvh_hierarchy_kernel, per_node, dim3(LBVH_THREADS), 0, s, (const unsigned long long*)keys_sorted, n, leaf_size,
                        walked, left, right, range_lo, range_hi, parent_of_node, parent_of_leaf);
     e = hipMemsetAsync(visits, 0, sizeof(unsigned) * ni, s);
@@ -1279,6 +1328,8 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   if (cur->d_normals) (void)hipFree(cur->d_normals);
   if (cur->d_bvh) (void)hipFree(cur->d_bvh);
   cur->d_tris = tris_out; b.release(tris_out);
+  if (cur->d_trif) (void)hipFree(cur->d_trif);
+  cur->d_trif = trif_out; b.release(trif_out);
   cur->d_tri_primary = prim_out; b.release(prim_out);
   cur->d_normals = normals_out; b.release(normals_out);
   cur->d_bvh = nodes; b.release(nodes);
