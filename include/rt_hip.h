@@ -217,6 +217,8 @@ typedef struct rt_stats {
    * (RayTracer.c:943-966, 923-940).  How many did: */
   uint64_t tri_exact;       /* of the triangle tests in prim_tests                */
   uint64_t sphere_exact;    /* of sphere_tests                                    */
+  double exchange_ms;       /* rt_hip_render_multi: hipEvent time on device 0 from the end of its own kernel
+                               until every device's rows are in place (RCCL receive + placement); else 0 */
 } rt_stats;
 
 /* Create the context of HIP device `device` (stream, events) if it does not
@@ -315,6 +317,34 @@ int rt_hip_format_ppm(const void* rgb_device, int width, int height, char* text_
  * bytes of canvas.ppm.  stats may be NULL. */
 int rt_hip_render_ppm(const rt_render_params* params, char* text_host, size_t capacity, size_t* bytes_out,
                       rt_stats* stats);
+
+/* ---- several GPUs driven by one host process ----
+ * The reference is one process and one render(camera*, world*) call (RayTracer.c:1574, 7236-7251); a C host that
+ * has several MI355X renders the frame on all of them: the scene is replicated, the image rows are dealt out in
+ * round-robin bands, and the bands come together on device 0 in ONE exchange step over xGMI (a grouped RCCL
+ * send/recv: every device sends its rows straight to device 0).  RCCL is loaded (dlopen) by rt_hip_multi_init; a
+ * one-GPU host never touches it.  The image does not depend on the number of devices. */
+
+/* HIP devices visible to the process (0 if there is none or the runtime fails). */
+int rt_hip_device_count(void);
+/* Contexts for devices 0 .. n_devices-1 (0 = every visible device) and the RCCL communicators between them. */
+int rt_hip_multi_init(int n_devices);
+/* Number of devices in the group (0 before rt_hip_multi_init). */
+int rt_hip_multi_devices(void);
+/* rt_hip_upload_scene on every device of the group. */
+int rt_hip_multi_upload_scene(const rt_scene* scene);
+/* rt_hip_render over the group: the whole frame arrives in rgb_out (hsize * vsize * 3 bytes, host memory).
+ * params->n_ranks must be 1 and rank 0 (the library deals the bands out: band_rows > 1 sets the band height,
+ * otherwise 16 rows).  stats: counters summed over the devices, kernel_ms the longest kernel, exchange_ms the
+ * gather. */
+int rt_hip_render_multi(const rt_render_params* params, uint8_t* rgb_out, rt_stats* stats);
+
+/* Where rank `rank`'s packed rows start in a buffer that holds every rank's rows, rank after rank (bytes). */
+size_t rt_hip_gather_offset(int hsize, int vsize, int band_rows, int n_ranks, int rank);
+/* Device memory to device memory: the gathered buffer (every rank's packed rows, rank after rank) into image
+ * order, on `stream` (NULL = the library's).  The step after the exchange, on the root. */
+int rt_hip_place_bands_device(const void* gathered_device, void* rgb_out_device, int hsize, int vsize, int band_rows,
+                              int n_ranks, void* stream);
 
 /* Number of image rows that belong to `rank` (see rt_render_params). */
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank);

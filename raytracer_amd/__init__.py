@@ -5,7 +5,7 @@ host C helpers (include/rt_scene.h, raytracer_amd/host).  This package is the
 Python plumbing used by tests, bench.py and the multi-GPU gather.
 """
 from . import _ffi
-from .render import HipRenderer, RtError, make_params, ppm_bytes, rank_row_map
+from .render import HipRenderer, MultiRenderer, RtError, gather_offset, make_params, ppm_bytes, rank_row_map
 from .scene import Mat4, SceneBuilder, default_material, lighthouse_triangles, material_ext, scene_arrays, stock_scene
 
 __all__ = [

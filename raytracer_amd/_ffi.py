@@ -142,6 +142,7 @@ class Stats(C.Structure):
         ("accel_used", C.c_int32),
         ("tri_exact", C.c_uint64),
         ("sphere_exact", C.c_uint64),
+        ("exchange_ms", C.c_double),
     ]
 
     @property
@@ -224,6 +225,12 @@ def hip_lib():
         L.rt_hip_render.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_device.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_f64.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+        L.rt_hip_multi_init.argtypes = [C.c_int]
+        L.rt_hip_multi_upload_scene.argtypes = [C.POINTER(Scene)]
+        L.rt_hip_render_multi.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+        L.rt_hip_gather_offset.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rt_hip_gather_offset.restype = C.c_size_t
+        L.rt_hip_place_bands_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.rt_hip_rank_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_hip_rank_row_to_y.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_hip_event_record.argtypes = [C.c_int, C.c_void_p]
@@ -260,6 +267,13 @@ HIP_EXPORTS = [
     "rt_hip_format_ppm_device_noalloc",
     "rt_hip_format_ppm",
     "rt_hip_render_ppm",
+    "rt_hip_device_count",
+    "rt_hip_multi_init",
+    "rt_hip_multi_devices",
+    "rt_hip_multi_upload_scene",
+    "rt_hip_render_multi",
+    "rt_hip_gather_offset",
+    "rt_hip_place_bands_device",
     "rt_hip_rank_rows",
     "rt_hip_rank_row_to_y",
     "rt_hip_event_record",

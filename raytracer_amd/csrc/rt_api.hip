@@ -10,6 +10,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -769,8 +772,17 @@ int check_params(const rt_render_params* p) {
   return RT_OK;
 }
 
-/* enqueue one render on `s`; waits and fills stats only when stats != NULL */
-int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats) {
+/* What render_enqueue launched, for render_collect. */
+struct Enqueued {
+  int rows = 0;
+  int accel_used = RT_ACCEL_BRUTE;
+  bool timed = false, count = false;
+};
+
+/* Enqueue one render of the current context's scene on `s` and return at once.  timed: record the context's
+ * event pair around the kernel; count: the counting build, counters zeroed first. */
+int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, bool timed, bool count,
+                   Enqueued* out) {
   const int W = cur->scene.hsize, H = cur->scene.vsize;
   const int rows = rt_hip_rank_rows(H, p->band_rows, p->n_ranks, p->rank);
   RenderArgs a;
@@ -787,10 +799,8 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   bool bvh = cur->scene.n_bvh_nodes > 0 && cur->scene.n_tris > 0;
   if (p->accel == RT_ACCEL_BRUTE) bvh = false;
   if (p->accel == RT_ACCEL_AUTO && cur->scene.n_tris < 32) bvh = false; /* a handful of triangles: the walk costs more */
-  const bool count = p->count_rays != 0 && stats != nullptr;
   const bool reflect = cur->reflective && p->max_depth >= 1;
   const bool overlap = (p->flags & RT_RENDER_FRAMES_OVERLAP) != 0;
-  if (stats) memset(stats, 0, sizeof *stats);
   if (rows > 0) {
     if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 8 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
@@ -808,40 +818,152 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
       const int prc = plan_tiles(p, rows, bvh, reflect, overlap, s, a, n_blocks);
       if (prc != RT_OK) return prc;
     }
-    (void)n_tiles;
     dim3 grid((unsigned)n_blocks);
-    if (stats) HIP_TRY(hipEventRecord(cur->ev0, s));
+    if (timed) HIP_TRY(hipEventRecord(cur->ev0, s));
     if (general) launch_general(count, grid, s, a, d_rgb, d_canvas);
     else launch(count, bvh, reflect, grid, s, a, d_rgb, d_canvas);
     HIP_TRY(hipGetLastError());
-    if (stats) HIP_TRY(hipEventRecord(cur->ev1, s));
+    if (timed) HIP_TRY(hipEventRecord(cur->ev1, s));
   }
-  if (stats) {
-    stats->rows_rendered = rows;
-    stats->accel_used = general ? RT_ACCEL_REFERENCE : (bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE);
-    if (rows > 0) {
-      HIP_TRY(hipEventSynchronize(cur->ev1));
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, cur->ev0, cur->ev1));
-      stats->kernel_ms = ms;
-      if (count) {
-        unsigned long long c[8];
-        HIP_TRY(hipMemcpyAsync(c, cur->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        stats->rays_primary = c[0];
-        stats->rays_shadow = c[1];
-        stats->rays_secondary = c[2];
-        stats->prim_tests = c[3];
-        stats->node_tests = c[4];
-        stats->sphere_tests = c[5];
-        stats->tri_exact = c[6];
-        stats->sphere_exact = c[7];
-      }
-    }
+  out->rows = rows;
+  out->accel_used = general ? RT_ACCEL_REFERENCE : (bvh ? RT_ACCEL_BVH : RT_ACCEL_BRUTE);
+  out->timed = timed;
+  out->count = count;
+  return RT_OK;
+}
+
+/* Wait for what render_enqueue launched on the current context and fill `stats`. */
+int render_collect(const Enqueued& e, hipStream_t s, rt_stats* stats) {
+  memset(stats, 0, sizeof *stats);
+  stats->rows_rendered = e.rows;
+  stats->accel_used = e.accel_used;
+  if (e.rows <= 0) return RT_OK;
+  if (e.timed) {
+    HIP_TRY(hipEventSynchronize(cur->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, cur->ev0, cur->ev1));
+    stats->kernel_ms = ms;
+  }
+  if (e.count) {
+    unsigned long long c[8];
+    HIP_TRY(hipMemcpyAsync(c, cur->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    stats->rays_primary = c[0];
+    stats->rays_shadow = c[1];
+    stats->rays_secondary = c[2];
+    stats->prim_tests = c[3];
+    stats->node_tests = c[4];
+    stats->sphere_tests = c[5];
+    stats->tri_exact = c[6];
+    stats->sphere_exact = c[7];
   }
   return RT_OK;
 }
 
+/* enqueue one render on `s`; waits and fills stats only when stats != NULL */
+int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats) {
+  Enqueued e;
+  const int rc = render_enqueue(p, d_rgb, d_canvas, s, stats != nullptr, p->count_rays != 0 && stats != nullptr, &e);
+  if (rc != RT_OK || !stats) return rc;
+  return render_collect(e, s, stats);
+}
+
+/* ---- several GPUs of one process: RCCL, loaded when first asked for ----
+ * The library does not link against librccl (half a gigabyte that a one-GPU host never needs): the handful of
+ * entry points the gather uses are looked up with dlopen/dlsym at rt_hip_multi_init. */
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int g_multi_n = 0;                  /* devices 0 .. g_multi_n - 1 form the group */
+ncclComm_t g_comms[kMaxDevices] = {};
+unsigned char* g_gather = nullptr;  /* device 0: every rank's packed rows, rank after rank */
+unsigned char* g_final = nullptr;   /* device 0: the rows in image order */
+size_t g_gather_bytes = 0;
+hipEvent_t g_multi_ev[kMaxDevices] = {}; /* device r's kernel is done (recorded on its stream) */
+hipEvent_t g_multi_t0 = nullptr, g_multi_t1 = nullptr; /* device 0: exchange + placement */
+
+bool rccl_ok(ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return true;
+  snprintf(g_err, sizeof g_err, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  return false;
+}
+#define RCCL_TRY(call)                              \
+  do {                                              \
+    if (!rccl_ok((call), #call)) return RT_ERR_HIP; \
+  } while (0)
+
+int load_rccl() {
+  if (g_rccl.lib) return RT_OK;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    snprintf(g_err, sizeof g_err, "dlopen librccl: %s", dlerror());
+    return RT_ERR_HIP;
+  }
+  Rccl r;
+  r.lib = lib;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(lib, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
+  r.Send = (decltype(r.Send))dlsym(lib, "ncclSend");
+  r.Recv = (decltype(r.Recv))dlsym(lib, "ncclRecv");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
+    snprintf(g_err, sizeof g_err, "librccl lacks an entry point the gather needs");
+    dlclose(lib);
+    return RT_ERR_HIP;
+  }
+  g_rccl = r;
+  return RT_OK;
+}
+
+void multi_teardown() {
+  for (int d = 0; d < g_multi_n; ++d) {
+    if (g_comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_comms[d]);
+    g_comms[d] = nullptr;
+    if (g_multi_ev[d]) { (void)hipSetDevice(d); (void)hipEventDestroy(g_multi_ev[d]); g_multi_ev[d] = nullptr; }
+  }
+  if (g_multi_n > 0) (void)hipSetDevice(0);
+  if (g_gather) (void)hipFree(g_gather);
+  if (g_final) (void)hipFree(g_final);
+  if (g_multi_t0) (void)hipEventDestroy(g_multi_t0);
+  if (g_multi_t1) (void)hipEventDestroy(g_multi_t1);
+  g_gather = g_final = nullptr;
+  g_gather_bytes = 0;
+  g_multi_t0 = g_multi_t1 = nullptr;
+  g_multi_n = 0;
+}
+
+/* Rows of the gathered buffer (rank after rank, each rank's rows packed in increasing y) into image order:
+ * out row y = rank (y / band_rows) % n_ranks's packed row.  16 bytes per thread where the row length allows. */
+__global__ __launch_bounds__(256) void place_bands_kernel(const unsigned char* __restrict__ gathered, unsigned char* __restrict__ out,
+                                                          int row_bytes, int vsize, int band_rows, int n_ranks) {
+  const int y = blockIdx.y;
+  const int band = y / band_rows, rank = band % n_ranks;
+  const int packed = (band / n_ranks) * band_rows + (y - band * band_rows);
+  /* rows of the ranks before `rank`: full rounds of bands, plus what the last, partial round gives them */
+  const int stride = band_rows * n_ranks, full = vsize / stride, rem = vsize % stride;
+  long long before = (long long)full * band_rows * rank;
+  before += min(rem, rank * band_rows);
+  const unsigned char* __restrict__ src = gathered + (before + packed) * (long long)row_bytes;
+  unsigned char* __restrict__ dst = out + (long long)y * row_bytes;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+  if (x + 16 <= row_bytes && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    *reinterpret_cast<uint4*>(dst + x) = *reinterpret_cast<const uint4*>(src + x);
+  } else {
+    for (int k = x; k < min(x + 16, row_bytes); ++k) dst[k] = src[k];
+  }
+}
 
 /* device allocations of one build: freed on every exit unless handed over */
 struct BuildBuffers {
@@ -1569,6 +1691,166 @@ int rt_hip_render_f64(const rt_render_params* p, double* canvas_out, rt_stats* s
   return RT_OK;
 }
 
+size_t rt_hip_gather_offset(int hsize, int vsize, int band_rows, int n_ranks, int rank) {
+  if (hsize < 0 || vsize < 0 || n_ranks < 1 || rank < 0 || rank > n_ranks || (n_ranks > 1 && band_rows < 1)) return 0;
+  size_t rows = 0;
+  for (int k = 0; k < rank; ++k) rows += (size_t)rt_hip_rank_rows(vsize, band_rows, n_ranks, k);
+  return rows * (size_t)hsize * 3;
+}
+
+int rt_hip_place_bands_device(const void* gathered_device, void* rgb_out_device, int hsize, int vsize, int band_rows, int n_ranks,
+                              void* stream) {
+  if (!cur->ready) return RT_ERR_NOT_READY;
+  if (!gathered_device || !rgb_out_device || hsize < 1 || vsize < 1 || n_ranks < 1 || band_rows < 1) return RT_ERR_INVALID;
+  if ((long long)hsize * 3 > (1ll << 30)) return RT_ERR_TOO_LARGE;
+  hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
+  const int row_bytes = hsize * 3;
+  const dim3 grid((unsigned)((row_bytes + 256 * 16 - 1) / (256 * 16)), (unsigned)vsize);
+  if (vsize > 65535) return RT_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(place_bands_kernel, grid, dim3(256), 0, s, (const unsigned char*)gathered_device, (unsigned char*)rgb_out_device,
+                     row_bytes, vsize, n_ranks > 1 ? band_rows : vsize, n_ranks);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+int rt_hip_multi_init(int n_devices) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+    snprintf(g_err, sizeof g_err, "no HIP device");
+    return RT_ERR_NO_DEVICE;
+  }
+  if (n_devices == 0) n_devices = n; /* every visible device */
+  if (n_devices < 1 || n_devices > n || n_devices > kMaxDevices) return RT_ERR_NO_DEVICE;
+  if (g_multi_n == n_devices) return RT_OK;
+  multi_teardown();
+  int rc = load_rccl();
+  if (rc != RT_OK) return rc;
+  for (int d = 0; d < n_devices; ++d)
+    if ((rc = rt_hip_init(d)) != RT_OK) return rc;
+  int devs[kMaxDevices];
+  for (int d = 0; d < n_devices; ++d) devs[d] = d;
+  RCCL_TRY(g_rccl.CommInitAll(g_comms, n_devices, devs));
+  g_multi_n = n_devices;
+  for (int d = 0; d < n_devices; ++d) {
+    HIP_TRY(hipSetDevice(d));
+    HIP_TRY(hipEventCreateWithFlags(&g_multi_ev[d], hipEventDisableTiming));
+  }
+  HIP_TRY(hipSetDevice(0));
+  HIP_TRY(hipEventCreate(&g_multi_t0));
+  HIP_TRY(hipEventCreate(&g_multi_t1));
+  return rt_hip_set_device(0);
+}
+
+int rt_hip_multi_upload_scene(const rt_scene* scene) {
+  if (g_multi_n < 1) return RT_ERR_NOT_READY;
+  for (int d = 0; d < g_multi_n; ++d) {
+    int rc = rt_hip_set_device(d);
+    if (rc == RT_OK) rc = rt_hip_upload_scene(scene);
+    if (rc != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+  }
+  return rt_hip_set_device(0);
+}
+
+int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) {
+  if (g_multi_n < 1) return RT_ERR_NOT_READY;
+  if (!p || !rgb_out) return RT_ERR_INVALID;
+  if (p->n_ranks != 1 || p->rank != 0) return RT_ERR_INVALID; /* the library deals the bands out itself */
+  const int n = g_multi_n;
+  int rc = rt_hip_set_device(0);
+  if (rc != RT_OK) return rc;
+  if ((rc = check_params(p)) != RT_OK) return rc;
+  const int W = cur->scene.hsize, H = cur->scene.vsize;
+  if (H > 65535) return RT_ERR_TOO_LARGE;
+  /* one tile row per band unless the caller says otherwise; fewer rows per band when the image is short, so
+   * that every device gets some (bands of 16 rows balance the compact lit region of mesh scenes) */
+  int band = p->band_rows > 1 ? p->band_rows : RT_TILE_H;
+  while (band > 1 && (H + band - 1) / band < 2 * n) band /= 2;
+  const size_t image_bytes = (size_t)W * H * 3;
+  if (image_bytes > g_gather_bytes) {
+    if (g_gather) (void)hipFree(g_gather);
+    if (g_final) (void)hipFree(g_final);
+    g_gather = g_final = nullptr;
+    g_gather_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g_gather, image_bytes));
+    HIP_TRY(hipMalloc((void**)&g_final, image_bytes));
+    g_gather_bytes = image_bytes;
+  }
+  rt_render_params q = *p;
+  q.band_rows = band;
+  q.n_ranks = n;
+  Enqueued enq[kMaxDevices];
+  size_t bytes[kMaxDevices], offset[kMaxDevices];
+  const bool want = stats != nullptr, count = want && p->count_rays != 0;
+  /* every device renders its bands: device 0 straight into its part of the gathered buffer */
+  for (int d = 0; d < n; ++d) {
+    if ((rc = rt_hip_set_device(d)) != RT_OK) return rc;
+    if (!cur->have_scene || cur->scene.hsize != W || cur->scene.vsize != H) { (void)rt_hip_set_device(0); return RT_ERR_NOT_READY; }
+    q.rank = d;
+    const int rows = rt_hip_rank_rows(H, band, n, d);
+    bytes[d] = (size_t)rows * W * 3;
+    offset[d] = rt_hip_gather_offset(W, H, band, n, d);
+    unsigned char* target = g_gather;
+    if (d > 0) {
+      if (bytes[d] > cur->d_rgb_bytes) {
+        if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+        cur->d_rgb = nullptr;
+        cur->d_rgb_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes[d] ? bytes[d] : 16));
+        cur->d_rgb_bytes = bytes[d];
+      }
+      target = cur->d_rgb;
+    }
+    if ((rc = render_enqueue(&q, target, nullptr, cur->stream, want, count, &enq[d])) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+  }
+  /* one exchange step: every other device sends its rows to device 0 over its own link (a grouped send/recv:
+   * the gather has a fixed root and unequal parts, which no single RCCL collective expresses) */
+  if ((rc = rt_hip_set_device(0)) != RT_OK) return rc;
+  hipStream_t s0 = cur->stream;
+  if (want) HIP_TRY(hipEventRecord(g_multi_t0, s0));
+  if (n > 1) {
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int d = 1; d < n; ++d) {
+      if (bytes[d] == 0) continue;
+      RCCL_TRY(g_rccl.Send(g_ctx[d].d_rgb, bytes[d], ncclUint8, 0, g_comms[d], g_ctx[d].stream));
+      RCCL_TRY(g_rccl.Recv(g_gather + offset[d], bytes[d], ncclUint8, d, g_comms[0], s0));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+  }
+  if ((rc = rt_hip_place_bands_device(g_gather, g_final, W, H, band, n, s0)) != RT_OK) return rc;
+  if (want) HIP_TRY(hipEventRecord(g_multi_t1, s0));
+  HIP_TRY(hipMemcpyAsync(rgb_out, g_final, image_bytes, hipMemcpyDeviceToHost, s0));
+  HIP_TRY(hipStreamSynchronize(s0));
+  if (want) {
+    rt_stats sum;
+    memset(&sum, 0, sizeof sum);
+    for (int d = 0; d < n; ++d) {
+      rt_stats one;
+      if ((rc = rt_hip_set_device(d)) != RT_OK) return rc;
+      if ((rc = render_collect(enq[d], cur->stream, &one)) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+      sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
+      sum.prim_tests += one.prim_tests; sum.node_tests += one.node_tests; sum.sphere_tests += one.sphere_tests;
+      sum.tri_exact += one.tri_exact; sum.sphere_exact += one.sphere_exact;
+      if (one.kernel_ms > sum.kernel_ms) sum.kernel_ms = one.kernel_ms; /* the devices run side by side */
+      sum.rows_rendered += one.rows_rendered;
+      sum.accel_used = one.accel_used;
+    }
+    if ((rc = rt_hip_set_device(0)) != RT_OK) return rc;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_multi_t0, g_multi_t1));
+    sum.exchange_ms = ms;
+    *stats = sum;
+  }
+  return RT_OK;
+}
+
+int rt_hip_multi_devices(void) { return g_multi_n; }
+
+int rt_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
 int rt_hip_event_record(int which, void* stream) {
   if (!cur->ready) return RT_ERR_NOT_READY;
   if (which != 0 && which != 1) return RT_ERR_INVALID;
@@ -1588,6 +1870,7 @@ int rt_hip_event_elapsed_ms(double* ms_out) {
 }
 
 void rt_hip_shutdown(void) {
+  multi_teardown();
   for (int d = 0; d < kMaxDevices; ++d)
     if (g_ctx[d].ready || g_ctx[d].stream) destroy_context(&g_ctx[d]);
   cur = &g_ctx[0];

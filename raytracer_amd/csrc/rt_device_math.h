@@ -57,6 +57,17 @@ __device__ __forceinline__ d3 div3_by(d3 a, double m) {
   }
   return mk3(a.x / m, a.y / m, a.z / m);
 }
+/* 1.0 / m, same construction (1 * y is exact, so the quotient estimate is y itself) */
+__device__ __forceinline__ double recip_ieee(double m) {
+  const double am = fabs(m);
+  if (am > 1e-100 && am < 1e100) {
+    double y = __builtin_amdgcn_rcp(m);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-m, y, 1.0), y);
+    return __builtin_fma(__builtin_fma(-m, y, 1.0), y, y);
+  }
+  return 1.0 / m;
+}
 /* two quotients by one divisor, same construction */
 __device__ __forceinline__ void div2_by(double a, double b, double m, double& qa, double& qb) {
   const double am = fabs(m);

@@ -4,7 +4,7 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
- *                 [--host-ppm] [--reference-list] [--device-bvh]
+ *                 [--host-ppm] [--reference-list] [--device-bvh] [--gpus N] [--frames K] [--json]
  *
  * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres, refraction,
  * world_with_plane, dual_spheres.
@@ -12,6 +12,9 @@
  * reading ./lighthouse.obj.  The P3 text of the file is formatted on the GPU (rt_hip_render_ppm) unless
  * --host-ppm asks for the C writer rt_write_ppm; both emit the bytes of write_canvas_to_file (:1333).
  * --device-bvh skips the host's SAH tree and builds one on the GPU (rt_hip_build_bvh_device).
+ * --gpus N (0 = every visible device) renders the frame on N GPUs of this process (rt_hip_render_multi: row bands,
+ * one RCCL gather to device 0); --frames K repeats the render K times and reports the mean wall time per frame;
+ * --json prints one line of figures for scripts.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,7 +40,7 @@ int main(int argc, char** argv) {
   const char* obj = "lighthouse.obj";
   const char* tris_f32 = NULL;
   const char* out = "canvas.ppm";
-  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
+  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0, gpus = -1, frames = 1, json = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
   double tri_refl = 0.0, sph_refl = 0.0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
@@ -53,6 +56,9 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--reference-list")) accel = RT_ACCEL_REFERENCE;
     else if (!strcmp(argv[i], "--host-ppm")) host_ppm = 1;
     else if (!strcmp(argv[i], "--device-bvh")) device_bvh = 1;
+    else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--json")) json = 1;
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -65,10 +71,10 @@ int main(int argc, char** argv) {
     if (tris_f32) {
       FILE* f = fopen(tris_f32, "rb");
       if (!f) { perror(tris_f32); return 1; }
-      fseek(f, 0, SEEK_END);
-      long n = ftell(f);
-      rewind(f);
-      float* v = malloc((size_t)n);
+      long n = -1;
+      if (fseek(f, 0, SEEK_END) == 0) n = ftell(f);
+      if (n < 0 || fseek(f, 0, SEEK_SET) != 0) { perror(tris_f32); return 1; }
+      float* v = malloc((size_t)n + 1);
       if (!v || fread(v, 1, (size_t)n, f) != (size_t)n) { perror(tris_f32); return 1; }
       fclose(f);
       rc = rt_scene_add_triangles_f32(b, v, (int)(n / (9 * sizeof(float))), NULL);
@@ -82,9 +88,17 @@ int main(int argc, char** argv) {
   rt_scene s;
   if ((rc = rt_scene_finish(b, device_bvh ? 0 : 4, &s)) != RT_OK) return fail("rt_scene_finish", rc);
 
-  if ((rc = rt_hip_init(device)) != RT_OK) return fail("rt_hip_init", rc);
-  if ((rc = rt_hip_upload_scene(&s)) != RT_OK) return fail("rt_hip_upload_scene", rc);
-  if (device_bvh) {
+  const int multi = gpus >= 0;
+  if (frames < 1) frames = 1;
+  if (multi) {
+    host_ppm = 1; /* the gathered image comes back as 8-bit rows; the C writer emits the file */
+    if ((rc = rt_hip_multi_init(gpus)) != RT_OK) return fail("rt_hip_multi_init", rc);
+    if ((rc = rt_hip_multi_upload_scene(&s)) != RT_OK) return fail("rt_hip_multi_upload_scene", rc);
+  } else {
+    if ((rc = rt_hip_init(device)) != RT_OK) return fail("rt_hip_init", rc);
+    if ((rc = rt_hip_upload_scene(&s)) != RT_OK) return fail("rt_hip_upload_scene", rc);
+  }
+  if (device_bvh && !multi) {
     rt_bvh_device_info info;
     if ((rc = rt_hip_build_bvh_device(4, &info)) != RT_OK) return fail("rt_hip_build_bvh_device", rc);
     printf("BVH built on the device: %d nodes, depth %d, %.3f ms\n", info.n_nodes, info.depth, info.build_ms);
@@ -98,7 +112,9 @@ int main(int argc, char** argv) {
   rt_stats st;
   printf("Starting Render Process\n");
   double t0 = now_s();
-  if (host_ppm) {
+  if (multi) {
+    if ((rc = rt_hip_render_multi(&p, buf, &st)) != RT_OK) return fail("rt_hip_render_multi", rc);
+  } else if (host_ppm) {
     if ((rc = rt_hip_render(&p, buf, &st)) != RT_OK) return fail("rt_hip_render", rc);
   } else {
     if ((rc = rt_hip_render_ppm(&p, (char*)buf, cap, &text_len, &st)) != RT_OK) return fail("rt_hip_render_ppm", rc);
@@ -110,6 +126,30 @@ int main(int argc, char** argv) {
          (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,
          (unsigned long long)st.rays_secondary, st.kernel_ms, rays / (st.kernel_ms * 1e3),
          st.accel_used == RT_ACCEL_BVH ? "BVH" : (st.accel_used == RT_ACCEL_REFERENCE ? "reference list" : "brute force"));
+  double per_frame_ms = dt * 1e3, kernel_ms = st.kernel_ms, exchange_ms = st.exchange_ms;
+  if (frames > 1) { /* steady state: the same frame again and again, wall time per frame (image to host memory) */
+    rt_render_params q = p;
+    q.count_rays = 0;
+    rt_stats s2;
+    double ksum = 0.0, xsum = 0.0;
+    for (int k = 0; k < 3; ++k) rc = multi ? rt_hip_render_multi(&q, buf, &s2) : rt_hip_render(&q, buf, &s2);
+    t0 = now_s();
+    for (int k = 0; k < frames && rc == RT_OK; ++k) {
+      rc = multi ? rt_hip_render_multi(&q, buf, &s2) : rt_hip_render(&q, buf, &s2);
+      ksum += s2.kernel_ms;
+      xsum += s2.exchange_ms;
+    }
+    if (rc != RT_OK) return fail("render", rc);
+    per_frame_ms = (now_s() - t0) * 1e3 / frames;
+    kernel_ms = ksum / frames;
+    exchange_ms = xsum / frames;
+    printf("%d frames: %.4f ms per frame to host memory (kernel %.4f ms, exchange %.4f ms)\n", frames, per_frame_ms, kernel_ms,
+           exchange_ms);
+  }
+  if (json)
+    printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"gpus\": %d, \"rays\": %llu, "
+           "\"first_call_ms\": %.4f, \"frames\": %d, \"ms_per_frame\": %.5f, \"kernel_ms\": %.5f, \"exchange_ms\": %.5f}\n",
+           scene, W, H, G, multi ? rt_hip_multi_devices() : 1, rays, dt * 1e3, frames, per_frame_ms, kernel_ms, exchange_ms);
   printf("Writing Canvas To File\n");
   if (host_ppm) {
     if ((rc = rt_write_ppm(out, buf, W, H)) != RT_OK) return fail("rt_write_ppm", rc);

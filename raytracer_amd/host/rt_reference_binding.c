@@ -72,6 +72,25 @@ int rt_render_hip(camera* c, world* w) {
   }
   rt_scene s;
   if (rc >= 0) rc = rt_scene_finish(b, 4, &s);
+  if (rc == RT_OK && rt_hip_device_count() > 1) {
+    /* several MI355X: every device renders its row bands, one RCCL gather brings the 8-bit rows to device 0.
+     * canvas[][] then holds the centre of each 8-bit step, which color_convert (RayTracer.c:1322) maps back to
+     * the same byte, so write_canvas_to_file() emits the same file. */
+    static uint8_t rgb[HORIZONTAL_SIZE * VERTICAL_SIZE * 3];
+    rt_render_params p = {RECURSION_DEPTH, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, 0};
+    rc = rt_hip_multi_init(0);
+    if (rc == RT_OK) rc = rt_hip_multi_upload_scene(&s);
+    if (rc == RT_OK) rc = rt_hip_render_multi(&p, rgb, NULL);
+    if (rc == RT_OK)
+      for (int y = 0; y < VERTICAL_SIZE; ++y)
+        for (int x = 0; x < HORIZONTAL_SIZE; ++x) {
+          const uint8_t* px = rgb + ((size_t)y * HORIZONTAL_SIZE + x) * 3;
+          tuple col = {(px[0] + 0.5) / 255.0, (px[1] + 0.5) / 255.0, (px[2] + 0.5) / 255.0, 1.0};
+          write_pixel(x, y, col);
+        }
+    rt_scene_destroy(b);
+    return rc;
+  }
   if (rc == RT_OK) rc = rt_hip_init(0);
   if (rc == RT_OK) rc = rt_hip_upload_scene(&s);
   if (rc == RT_OK) {

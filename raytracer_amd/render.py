@@ -132,6 +132,11 @@ class HipRenderer:
         _check(self._L.rt_hip_render_ppm(C.byref(p), buf.ctypes.data, cap, C.byref(n), C.byref(st)), "rt_hip_render_ppm")
         return buf[: n.value].tobytes(), st
 
+    def place_bands_device(self, gathered_ptr, out_ptr, width, height, band_rows, n_ranks, stream=None):
+        """Gathered buffer (every rank's packed rows, rank after rank) -> image order, device to device."""
+        _check(self._L.rt_hip_place_bands_device(C.c_void_p(gathered_ptr), C.c_void_p(out_ptr), width, height, band_rows,
+                                                 n_ranks, C.c_void_p(stream or 0)), "rt_hip_place_bands_device")
+
     def timer_start(self, stream=None):
         _check(self._L.rt_hip_event_record(0, C.c_void_p(stream or 0)), "rt_hip_event_record")
 
@@ -145,6 +150,38 @@ class HipRenderer:
 
     def shutdown(self):
         self._L.rt_hip_shutdown()
+
+
+class MultiRenderer:
+    """Several GPUs driven by this one process (rt_hip_multi_*): bands rendered on every device, gathered on
+    device 0 with RCCL, one image back.  n_devices=0: every visible device."""
+
+    def __init__(self, n_devices=0):
+        self._L = _ffi.hip_lib()
+        _check(self._L.rt_hip_multi_init(int(n_devices)), "rt_hip_multi_init")
+        self.n_devices = int(self._L.rt_hip_multi_devices())
+        self._scene = None
+
+    def upload(self, scene):
+        _check(self._L.rt_hip_multi_upload_scene(C.byref(scene)), "rt_hip_multi_upload_scene")
+        self._scene = scene
+        self.width, self.height = scene.camera.hsize, scene.camera.vsize
+        return self
+
+    def render(self, params=None, stats=True, **kw):
+        p = params or make_params(**kw)
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        st = Stats()
+        _check(self._L.rt_hip_render_multi(C.byref(p), out.ctypes.data, C.byref(st) if stats else None), "rt_hip_render_multi")
+        return out, st
+
+    def shutdown(self):
+        self._L.rt_hip_shutdown()
+
+
+def gather_offset(width, height, band_rows, n_ranks, rank):
+    """Byte offset of `rank`'s packed rows in a buffer holding every rank's rows, rank after rank."""
+    return int(_ffi.hip_lib().rt_hip_gather_offset(width, height, band_rows, n_ranks, rank))
 
 
 def rank_row_map(height, band_rows, n_ranks, rank):
