@@ -5,22 +5,29 @@
 
 One step = one render() of the frame: every rank traces its round-robin row
 bands on its own MI355X and (N > 1) the 8-bit rows are exchanged with RCCL so
-that frame f is complete on rank f % N (one all-to-all per group of frames).  The scene is uploaded before the timed region; nothing crosses PCIe
-inside it.  Rank 0 prints one JSON line.
+that frame f is complete on rank f % N (one all-to-all per group of frames).
+The scene is uploaded before the timed region; nothing crosses PCIe inside it.
+Rank 0 prints one JSON line.
 
-  value        total rays (primary + shadow + secondary, the reference's
+  value        total rays (primary + shadow + secondary: the reference's
                intersect_world call count) of all ranks / wall time, Mrays/s
-  roofline     the trace kernel against the FP32 vector peak (the path is
-               VALU-bound: the scene lives in SGPRs/caches, 3 bytes per pixel
-               are written); algorithmic FLOPs = rays x primitives x 45
+  roofline     the trace kernel against the FP32 vector peak.  achieved = the
+               FLOPs the kernel EXECUTED (its own counters: single-precision
+               filter tests, double-precision confirms, box tests, ray set-up,
+               shading) / kernel time.  The exhaustive figure rays x
+               primitives x 45 (what the reference's loop over every object
+               costs) is reported beside it as algorithmic_equivalent; it is
+               not what the hardware did.
   cpu_baseline the reference itself (oracle/_ref, gcc -O2, one core) on the
                same workload, timed on this host
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,40 +37,98 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import raytracer_amd as R  # noqa: E402
-from raytracer_amd.dist import FrameExchange, default_band_rows  # noqa: E402
+from raytracer_amd.dist import BandGather, FrameExchange, default_band_rows  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "cube"  # render_some_triangles + the teapot.h mesh (12 triangles), RayTracer.c:6727
-# algorithmic FLOPs per unit of work (the figures the survey fixed for this path)
-FLOP_PER_TRI_TEST = 45      # full Moeller-Trumbore path, RayTracer.c:943-966
-FLOP_PER_SPHERE_TEST = 63   # two affine mat-vec + quadratic, RayTracer.c:898-940
-FLOP_PER_BOX_TEST = 18      # slab test (BVH node or mesh bounds)
+# FLOPs per unit of work.  Double precision, the reference's statements (no FMA: a multiply and an add are two):
+FLOP_TRI_EXACT = 45         # full Moeller-Trumbore path, RayTracer.c:943-966
+FLOP_SPHERE_EXACT = 63      # two affine mat-vec + quadratic, RayTracer.c:898-940
 FLOP_PER_PRIMARY_RAY = 30   # ray_for_pixel, RayTracer.c:1535
 FLOP_PER_SHADED_HIT = 80    # prepare_computations + lighting (+ 1 pow), RayTracer.c:1360, 1273
-PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 128 lanes x 2 x 2.4 GHz)
+# Single precision, the conservative first tests (an FMA counts two):
+FLOP_TRI_FILTER = 34        # three dot-product chains of 3 + 6 + 6 terms, two subtractions, max3/min3
+FLOP_SPHERE_FILTER = 54     # o', d' (two mat-vec), cross product, two squared norms; 36 when o' is the camera's
+FLOP_SPHERE_FILTER_PRIMARY = 36
+FLOP_PER_BOX_TEST = 18      # slab test (BVH node or mesh bounds)
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 128 lanes x 2 x 2.4 GHz)
 PEAK_FP64_NO_FMA_TFLOPS = 39.3  # FP64 vector: 78.6 with FMA, half of it for a mul/add-only stream
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_cube_1080p.json")
+LIGHTHOUSE_BIN = os.path.join(ROOT, "raytracer_amd", "data", "lighthouse_tris_f32.bin")
+CLI = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer_hip")
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the headline kernel, from the committed summary of the PMC passes (a bench run
-    cannot collect hardware counters itself); None when no summary is there."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_cube_1080p.json")
+def git_commit():
     try:
-        d = json.load(open(path))
-        return int(d["derived_hbm_read_bytes_corrected_x2"] + d["derived_hbm_write_bytes"])
-    except (OSError, KeyError, ValueError):
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
         return None
 
 
-def algorithmic_flops(st):
-    """FLOPs of the work the kernel actually did in one launch, from its own counters (counting build)."""
+def pmc_traffic():
+    """HBM bytes per launch of the headline kernel, from the committed summary of separate rocprofv3 --pmc passes (a
+    bench run cannot collect hardware counters itself), with the file and the commit it was taken at."""
+    try:
+        d = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
+        return int(d["derived_hbm_read_bytes_corrected_x2"] + d["derived_hbm_write_bytes"]), {"file": PMC_SUMMARY,
+                                                                                             "commit": d.get("_commit")}
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def executed_flops(st, n_spheres, brute):
+    """(single-precision FLOPs, double-precision FLOPs) of the work one launch really did, from the counting
+    build's counters.  Exhaustive kernels run the single-precision test on every triangle and confirm the
+    survivors in double precision; the BVH walk tests a leaf's triangles in double precision directly."""
     tri_tests = st.prim_tests - st.sphere_tests
-    return (st.rays_primary * FLOP_PER_PRIMARY_RAY + st.rays_shadow * FLOP_PER_SHADED_HIT
-            + tri_tests * FLOP_PER_TRI_TEST + st.sphere_tests * FLOP_PER_SPHERE_TEST + st.node_tests * FLOP_PER_BOX_TEST)
+    sph_primary = min(st.sphere_tests, st.rays_primary * n_spheres)
+    f32 = ((tri_tests * FLOP_TRI_FILTER if brute else 0) + sph_primary * FLOP_SPHERE_FILTER_PRIMARY
+           + (st.sphere_tests - sph_primary) * FLOP_SPHERE_FILTER + st.node_tests * FLOP_PER_BOX_TEST)
+    f64 = (st.tri_exact * FLOP_TRI_EXACT + st.sphere_exact * FLOP_SPHERE_EXACT + st.rays_primary * FLOP_PER_PRIMARY_RAY
+           + st.rays_shadow * FLOP_PER_SHADED_HIT)
+    return f32, f64
 
 
-def side_measurements(hip, dev, steps=100):
-    """Context for the headline: the other benchmark scenes at 1920x1080 on this GPU, kernel time from HIP events."""
+def roofline_of(st, n_spheres, n_tris, ms):
+    """The roofline object of one kernel launch that took `ms`."""
+    brute = st.accel_used == R._ffi.RT_ACCEL_BRUTE
+    f32, f64 = executed_flops(st, n_spheres, brute)
+    total = f32 + f64
+    achieved = total / (ms * 1e-3) / 1e12
+    # what this mix of instructions could reach at most: each part at its own peak
+    ceiling = total / (f32 / PEAK_FP32_VALU_TFLOPS + f64 / PEAK_FP64_NO_FMA_TFLOPS) if total else 0.0
+    assert achieved <= ceiling * 1.0001, (achieved, ceiling)
+    exhaustive = st.rays * (n_tris * FLOP_TRI_EXACT + n_spheres * FLOP_SPHERE_EXACT)
+    return {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "kernel_ms": round(ms, 5),
+            "executed_flops_per_launch": {"fp32_fma": int(f32), "fp64_mul_add": int(f64)},
+            "ceiling_of_issued_mix_tflops": round(ceiling, 2), "frac_of_ceiling": round(achieved / ceiling, 4) if ceiling else None,
+            "algorithmic_equivalent": {"flops_per_launch": int(exhaustive), "tflops": round(exhaustive / (ms * 1e-3) / 1e12, 3),
+                                       "what": "rays x primitives x the full-path figure: the reference's loop over every "
+                                               "object; not executed here (bounds, single-precision first tests, BVH)"},
+            "counters": {"tri_tests": st.prim_tests - st.sphere_tests, "tri_exact": st.tri_exact, "sphere_tests": st.sphere_tests,
+                         "sphere_exact": st.sphere_exact, "box_tests": st.node_tests, "primary": st.rays_primary,
+                         "shaded": st.rays_shadow, "secondary": st.rays_secondary}}
+
+
+def time_launches(hip, buf, p, n, reps=3):
+    """Best mean kernel time (ms) of n back-to-back launches on the library's stream, HIP events around the batch."""
+    for _ in range(max(2, n // 5)):
+        hip.render_device(buf.data_ptr(), p)
+    best = None
+    for _ in range(reps):
+        hip.timer_start()
+        for _ in range(n):
+            hip.render_device(buf.data_ptr(), p)
+        hip.timer_stop()
+        ms = hip.timer_ms() / n
+        best = ms if best is None else min(best, ms)
+    return best
+
+
+def side_measurements(hip, dev):
+    """Context for the headline: the other benchmark scenes at 1920x1080 on this GPU, each with its own roofline."""
     out = {}
     buf = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     for name, scene, tr, accel in (("spheres_1080p", "spheres", 0.0, R._ffi.RT_ACCEL_AUTO),
@@ -73,23 +138,29 @@ def side_measurements(hip, dev, steps=100):
         hip.upload(R.stock_scene(scene, WIDTH, HEIGHT, tr))
         st = R._ffi.Stats()
         hip.render_device(buf.data_ptr(), R.make_params(accel=accel, count_rays=True), stats=st)
-        p = R.make_params(accel=accel)
-        n = steps if accel != R._ffi.RT_ACCEL_BRUTE else 10
-        for _ in range(3):
-            hip.render_device(buf.data_ptr(), p)
-        hip.timer_start()
-        for _ in range(n):
-            hip.render_device(buf.data_ptr(), p)
-        hip.timer_stop()
-        ms = hip.timer_ms() / n
-        executed = algorithmic_flops(st)
+        ms = time_launches(hip, buf, R.make_params(accel=accel), 100 if accel != R._ffi.RT_ACCEL_BRUTE else 10)
         sc = hip.scene_counts()
-        exhaustive = st.rays * (sc[1] * FLOP_PER_TRI_TEST + sc[0] * FLOP_PER_SPHERE_TEST)
-        fl = exhaustive if st.accel_used == R._ffi.RT_ACCEL_BRUTE else executed
-        out[name] = {"rays": st.rays, "kernel_ms": round(ms, 5), "mrays_s": round(st.rays / ms / 1e3, 1),
-                     "tflops_algorithmic": round(fl / ms / 1e9, 3), "tflops_executed": round(executed / ms / 1e9, 3),
-                     "tri_tests": st.prim_tests - st.sphere_tests,
-                     "sphere_tests": st.sphere_tests, "box_tests": st.node_tests}
+        rf = roofline_of(st, sc[0], sc[1], ms)
+        out[name] = {"rays": st.rays, "kernel_ms": round(ms, 5), "mrays_s": round(st.rays / ms / 1e3, 1), "roofline": rf}
+    return out
+
+
+def full_size_configs(hip, dev):
+    """The two multi-GPU configurations at full size on this one GPU: C4 (4K lighthouse, mesh reflective 0.3, BVH) and
+    C5 (8K, 16 spp, cube + spheres, reflective)."""
+    out = {}
+    for name, scene, w, h, tr, sr, spp, accel, n in (
+            ("C4_lighthouse_3840x2160_reflective_bvh", "lighthouse", 3840, 2160, 0.3, 0.0, 1, R._ffi.RT_ACCEL_BVH, 20),
+            ("C5_cube_spheres_7680x4320_16spp_reflective", "cube_spheres", 7680, 4320, 0.3, 0.3, 4, R._ffi.RT_ACCEL_AUTO, 3)):
+        hip.upload(R.stock_scene(scene, w, h, tr, sr))
+        buf = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        st = R._ffi.Stats()
+        hip.render_device(buf.data_ptr(), R.make_params(spp_grid=spp, accel=accel, count_rays=True), stats=st)
+        ms = time_launches(hip, buf, R.make_params(spp_grid=spp, accel=accel), n, reps=2)
+        sc = hip.scene_counts()
+        out[name] = {"rays": st.rays, "kernel_ms": round(ms, 4), "mrays_s": round(st.rays / ms / 1e3, 1),
+                     "roofline": roofline_of(st, sc[0], sc[1], ms)}
+        del buf
     return out
 
 
@@ -138,14 +209,7 @@ def general_measurements(hip, dev, steps=20):
         hip.upload(R.stock_scene(scene, WIDTH, HEIGHT))
         st = R._ffi.Stats()
         hip.render_device(buf.data_ptr(), R.make_params(count_rays=True), stats=st)
-        p = R.make_params()
-        for _ in range(2):
-            hip.render_device(buf.data_ptr(), p)
-        hip.timer_start()
-        for _ in range(steps):
-            hip.render_device(buf.data_ptr(), p)
-        hip.timer_stop()
-        ms = hip.timer_ms() / steps
+        ms = time_launches(hip, buf, R.make_params(), steps, reps=1)
         out[scene + "_1080p"] = {"rays": st.rays, "kernel_ms": round(ms, 4), "mrays_s": round(st.rays / ms / 1e3, 1)}
     return out
 
@@ -171,6 +235,58 @@ def ppm_measurements(hip, dev, steps=50):
             "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes}}
         del img, text
+    return out
+
+
+def run_json(cmd, timeout, cwd=None):
+    """Run a child process whose last stdout line starting with '{' is JSON; (dict or None, wall seconds, error text)."""
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=cwd)
+    except (OSError, subprocess.SubprocessError) as e:
+        return None, time.perf_counter() - t0, repr(e)
+    dt = time.perf_counter() - t0
+    if out.returncode != 0:
+        return None, dt, (out.stderr or out.stdout)[-300:]
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line), dt, None
+    return {}, dt, None
+
+
+def first_call_measurements():
+    """What a drop-in user gets: one process, one render, one canvas.ppm (the reference's main(), RayTracer.c:7236-7251).
+    (a) the headline frame through the C host in a fresh process: time of rt_hip_init, of the upload and of the first
+    rt_hip_render (production kernel), then the steady state.  (b) configuration 1 (lighthouse, 300x300) end to end,
+    process start to canvas.ppm written, next to the reference's own code on one host core (same mesh, same file)."""
+    out = {}
+    if not os.path.exists(CLI):
+        return {"error": "raytracer_amd/bin/raytracer_hip is missing"}
+    with tempfile.TemporaryDirectory() as tmp:
+        info, wall, err = run_json([CLI, SCENE, "--size", str(WIDTH), str(HEIGHT), "--host-ppm", "--no-count", "--frames", "50",
+                                    "--json", "--out", os.path.join(tmp, "a.ppm")], 120)
+        out["headline_frame_fresh_process"] = info if info else {"error": err}
+        if info:
+            out["first_call_ms"] = info.get("first_call_ms")
+        hip_ppm, ref_ppm = os.path.join(tmp, "hip.ppm"), os.path.join(tmp, "ref.ppm")
+        info, wall, err = run_json([CLI, "lighthouse", "--tris-f32", LIGHTHOUSE_BIN, "--json", "--out", hip_ppm], 120)
+        c1 = {"hip_process_wall_s": round(wall, 4), "hip": info if info else {"error": err}}
+        ref = os.path.join(ROOT, "oracle", "_ref", "rt_ref_harness_timing")
+        if os.path.exists(ref):
+            rinfo, rwall, rerr = run_json([ref, "--scene", "lighthouse", "--tris-f32", LIGHTHOUSE_BIN, "--out-ppm", ref_ppm], 300)
+            c1["reference_process_wall_s"] = round(rwall, 4)
+            if rinfo:
+                c1["reference_pixel_loop_s"] = rinfo.get("seconds")
+                c1["speedup_process_wall"] = round(rwall / wall, 2)
+                try:
+                    sha = [hashlib.sha256(open(f, "rb").read()).hexdigest() for f in (hip_ppm, ref_ppm)]
+                    c1["canvas_ppm_identical"] = sha[0] == sha[1]
+                    c1["canvas_ppm_sha256"] = sha[0]
+                except OSError as e:
+                    c1["canvas_ppm_identical"] = repr(e)
+            else:
+                c1["reference_error"] = rerr
+        out["C1_lighthouse_300x300_one_shot"] = c1
     return out
 
 
@@ -224,13 +340,71 @@ def cpu_baseline(rays_expected):
             "seconds": round(dt, 3), "sample": f"every 8th row ({rows} rows) of {SCENE} {WIDTH}x{HEIGHT}"}
 
 
+def run_frames(render, fx, n_steps):
+    """n_steps frames through a FrameExchange: render(target) fills this rank's bands of a frame, groups of frames
+    are exchanged while the next group renders.  Returns how many complete frames this rank ends up holding."""
+    pending = [None, None]
+    held = 0
+    f, slot = 0, 0
+    while f < n_steps:
+        if pending[slot] is not None:  # the slot's previous group must have left before it is overwritten
+            held += len(fx.finish(pending[slot], slot))
+        n = min(fx.group, n_steps - f)
+        for j in range(n):
+            render(fx.target(slot, j))
+        pending[slot] = fx.exchange_async(slot, n)
+        f += n
+        slot ^= 1
+    for k in (slot, slot ^ 1):
+        if pending[k] is not None:
+            held += len(fx.finish(pending[k], k))
+    return held
+
+
+def gather_to_root(hip, dev, world, rank, scene_name, w, h, tr, sr, spp, accel, steps, rehearse):
+    """One frame at a time, the way a single render() call works over several GPUs: every rank renders its bands,
+    ONE gather brings them to rank 0, rank 0 puts the rows in place.  Wall time per frame, max over ranks."""
+    hip.upload(R.stock_scene(scene_name, w, h, tr, sr))
+    band_rows = default_band_rows(h, world)
+    bg = BandGather(h, w, band_rows, world, rank, dev)
+    p = R.make_params(spp_grid=spp, accel=accel, band_rows=band_rows, n_ranks=world, rank=rank)
+    st = R._ffi.Stats()
+    hip.render_device(bg.local.data_ptr(), R.make_params(spp_grid=spp, accel=accel, count_rays=True, band_rows=band_rows,
+                                                         n_ranks=world, rank=rank), stats=st)
+    stream = torch.cuda.current_stream().cuda_stream
+    t_stats = torch.tensor([float(st.rays)], dtype=torch.float64, device="cpu" if rehearse else dev)
+    dist.all_reduce(t_stats)
+    rays = int(t_stats.item())
+
+    def frame():
+        hip.render_device(bg.local.data_ptr(), p, stream=stream)
+        return bg.gather()
+
+    for _ in range(2):
+        frame()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearse else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) / steps * 1e3
+    kernel_ms = time_launches(hip, bg.local, p, max(3, steps // 2), reps=1)
+    del bg
+    return {"rays": rays, "ms_per_frame": round(ms, 4), "mrays_s": round(rays / ms / 1e3, 1), "rank0_kernel_ms": round(kernel_ms, 4),
+            "band_rows": band_rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side", action="store_true", help="skip the other-scenes context measurements")
+    ap.add_argument("--no-side", action="store_true", help="skip the context measurements beside the headline")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,32 +447,16 @@ def main():
     total_rays, _ = [int(x) for x in my_rays.tolist()]
     accel_used = "bvh" if st.accel_used == R._ffi.RT_ACCEL_BVH else "brute"
 
-    def run(n_steps):
-        """n_steps frames: render, exchange, assemble.  Returns how many complete frames this rank ends up holding."""
-        pending = [None, None]
-        held = 0
-        f, slot = 0, 0
-        while f < n_steps:
-            if pending[slot] is not None:  # the slot's previous group must have left before it is overwritten
-                held += len(fx.finish(pending[slot], slot))
-            n = min(fx.group, n_steps - f)
-            for j in range(n):
-                hip.render_device(fx.target(slot, j).data_ptr(), p, stream=stream)
-            pending[slot] = fx.exchange_async(slot, n)
-            f += n
-            slot ^= 1
-        for k in (slot, slot ^ 1):
-            if pending[k] is not None:
-                held += len(fx.finish(pending[k], k))
-        return held
+    def render(target):
+        hip.render_device(target.data_ptr(), p, stream=stream)
 
-    run(a.warmup)
+    run_frames(render, fx, a.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hip.timer_start(stream)
-    held = run(a.steps)
+    held = run_frames(render, fx, a.steps)
     hip.timer_stop(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -310,7 +468,7 @@ def main():
         dist.all_reduce(frames_held)
     assert int(frames_held.item()) == a.steps, "every timed frame must have been put together on some rank"
     if world > 1:
-        # the kernel alone (no gather between launches), for the roofline line
+        # the kernel alone (no exchange between launches), for the roofline line
         hip.timer_start(stream)
         for _ in range(50):
             hip.render_device(fx.target(0, 0).data_ptr(), p, stream=stream)
@@ -321,19 +479,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    line = None
     if rank == 0:
-        # per launch of THIS rank's kernel, from the counting build of the same kernel on the same rows
-        flops_per_launch = algorithmic_flops(st)
-        exhaustive_flops = st.rays * (scene.n_tris * FLOP_PER_TRI_TEST + scene.n_spheres * FLOP_PER_SPHERE_TEST)
         kernel_ms = ev_ms / a.steps  # HIP events on the launch stream around the K launches
-        # Algorithmic FLOPs of a launch.  Exhaustive kernel: rays x primitives x the full-path figure (what the
-        # reference's loop over every object costs); BVH kernel: the tests the walk actually made (counted).
-        if accel_used == "brute":
-            algorithmic = exhaustive_flops
-        else:
-            algorithmic = flops_per_launch
-        achieved = algorithmic / (kernel_ms * 1e-3) / 1e12
-        executed = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        rf = roofline_of(st, scene.n_spheres, scene.n_tris, kernel_ms)
+        traffic, source = pmc_traffic()
+        rf["traffic"] = traffic
+        rf["traffic_source"] = source
+        rf["kernel"] = "rt_trace_kernel"
+        rf["note"] = ("bound: vector ALU (the scene sits in LDS/scalar cache, 3 B per pixel are written). achieved = FLOPs the "
+                      "kernel executed (counting build of the same kernel on the same rows) / kernel time; peak = the FP32 "
+                      "vector peak the metric names. The executed mix is single-precision FMA (filter and box tests) and "
+                      "double-precision mul/add without FMA (confirms, ray set-up, shading: bit parity with the reference); "
+                      "ceiling_of_issued_mix prices each part at its own peak (157.3 and 39.3 TFLOP/s). traffic = HBM "
+                      "bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)")
         line = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080 teapot scene; % of FP32 VALU peak",
             "value": round(total_rays * a.steps / dt / 1e6, 2),
@@ -349,37 +508,50 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"teapot.h mesh (12 triangles), render_some_triangles camera/light, {WIDTH}x{HEIGHT}, "
                                    "1 spp, depth 5", "rays_per_frame": total_rays, "accel": accel_used,
+                       "rays_counted": "intersect_world calls: primary + shadow (+ reflected: none in this scene)",
                        "parallelism": f"row bands of {band_rows} rows round-robin over {world} rank(s)"
                                       + (f"; frame f is put together on rank f % {world}, one RCCL all-to-all per "
-                                         f"{fx.group} frames" if world > 1 else "")},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": pmc_traffic_bytes(), "kernel": "rt_trace_kernel", "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_flops_per_launch": algorithmic,
-                         "executed_tflops": round(executed, 3), "executed_flops_per_launch": flops_per_launch,
-                         "fp64_no_fma_ceiling_tflops": PEAK_FP64_NO_FMA_TFLOPS,
-                         "frac_of_fp64_no_fma_ceiling": round(achieved / PEAK_FP64_NO_FMA_TFLOPS, 4),
-                         "counters": {"tri_tests": st.prim_tests - st.sphere_tests, "sphere_tests": st.sphere_tests,
-                                      "box_tests": st.node_tests, "primary": st.rays_primary, "shaded": st.rays_shadow},
-                         "note": "bound: vector ALU (the scene sits in LDS/scalar cache, 3 B per pixel are written). "
-                                 "achieved = algorithmic FLOPs / kernel time: rays x 12 triangles x 45 for this exhaustive "
-                                 "kernel; executed = 30/primary ray + 80/shaded hit + 45/triangle test + 18/box test the "
-                                 "kernel really ran (a bounds test lets most rays skip the triangle loop). The arithmetic "
-                                 "is FP64 mul/add without FMA (bit parity with the reference), whose ceiling is 1/4 of the "
-                                 "FP32 vector peak priced here. traffic = HBM bytes per launch from separate rocprofv3 "
-                                 "--pmc passes over the same launch (profiles/), FETCH_SIZE x2 + WRITE_SIZE"},
+                                         f"{fx.group} frames" if world > 1 else ""),
+                       "commit": git_commit(),
+                       "note": "the first launches of a process run ~10 % slower while the clocks come up: --steps 20 "
+                               "--warmup 5 reads lower than the default 2000/300"},
+            "roofline": rf,
         }
-        if world == 1 and not a.no_cpu_baseline:
+    del fx
+    if world == 1 and rank == 0:
+        if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total_rays)
-        if world == 1 and not a.no_side:
+        if not a.no_side:
             line["other_scenes_1080p"] = side_measurements(hip, dev)
+            line["full_size_configs_one_gpu"] = full_size_configs(hip, dev)
             line["general_kernel_scenes"] = general_measurements(hip, dev)
             line["frames_pipelined_over_streams"] = pipelined_measurements(hip, dev)
             line["ppm_text_on_device_random_image"] = ppm_measurements(hip, dev)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if world > 1 and not a.no_side:
+        # What a single render() call over N GPUs costs (one gather to rank 0 per frame), for the headline frame and
+        # for the two configurations the row-band design is for.  Every rank takes part; rank 0 reports.
+        multi = {}
+        for name, args in (("headline_1080p", (SCENE, WIDTH, HEIGHT, 0.0, 0.0, 1, R._ffi.RT_ACCEL_AUTO, 200)),
+                           ("C4_lighthouse_3840x2160_reflective_bvh", ("lighthouse", 3840, 2160, 0.3, 0.0, 1, R._ffi.RT_ACCEL_BVH, 50)),
+                           ("C5_cube_spheres_7680x4320_16spp_reflective", ("cube_spheres", 7680, 4320, 0.3, 0.3, 4, R._ffi.RT_ACCEL_AUTO, 5))):
+            multi[name] = gather_to_root(hip, dev, world, rank, *args, rehearse)
+        if rank == 0:
+            line["single_frame_gather_to_rank0"] = multi
     hip.shutdown()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if not a.no_side and not rehearse:
+            if world == 1:
+                line["drop_in_first_call"] = first_call_measurements()
+            elif os.path.exists(CLI):
+                # the C host's own multi-GPU path (one process, N devices, RCCL gather): a child process of rank 0
+                # after the ranks are done, so that a failure there cannot take the line above with it
+                info, wall, err = run_json([CLI, SCENE, "--size", str(WIDTH), str(HEIGHT), "--gpus", str(world), "--no-count",
+                                            "--frames", "100", "--json", "--out", os.path.join(tempfile.gettempdir(), "rt_multi.ppm")], 180)
+                line["c_host_render_multi"] = info if info else {"error": err, "wall_s": round(wall, 2)}
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -95,14 +95,29 @@ static scene_t scene_cube(int hs, int vs) { /* render_some_triangles, RayTracer.
   return s;
 }
 
-static scene_t scene_lighthouse(int hs, int vs, const char* obj) { /* render_lighthouse_scene, RayTracer.c:6772 */
+/* The triangles load_model_file() would make, from a file of 9 floats per triangle (the positions it reads out of
+ * objpar's float array, RayTracer.c:1657-1667, in face order): widened to double and handed to the reference's own
+ * create_triangle / add_shape_to_world (RayTracer.c:1669), as load_model_file does.  For hosts where the OBJ text
+ * is not present. */
+static void append_triangles_f32(world* w, const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  float v[9];
+  while (fread(v, sizeof(float), 9, f) == 9)
+    add_shape_to_world(create_triangle(create_point(v[0], v[1], v[2]), create_point(v[3], v[4], v[5]),
+                                       create_point(v[6], v[7], v[8])), w);
+  fclose(f);
+}
+
+static scene_t scene_lighthouse(int hs, int vs, const char* obj, const char* tris_f32) { /* render_lighthouse_scene, RayTracer.c:6772 */
   scene_t s;
   s.w = create_world();
   s.c = create_camera(hs, vs, 0.5);
   view_transform(create_point(24.0, 18.0, -5.0), create_point(0.0, 2.1, 0.0), create_vector(0.0, 1.0, 0.0),
                  s.c->view_transform);
   *s.w.lights = create_point_light(create_point(2.0, 10.0, -5.0), create_point(0.9, 0.9, 0.9));
-  load_model_file((char*)obj, &s.w);
+  if (tris_f32) append_triangles_f32(&s.w, tris_f32);
+  else load_model_file((char*)obj, &s.w);
   return s;
 }
 
@@ -284,7 +299,7 @@ static double now_s(void) {
 static void usage(void) {
   fprintf(stderr,
           "rt_ref_harness --scene lighthouse|cube|spheres|cube_spheres [--size W H] [--spp-grid G]\n"
-          "   [--tri-reflective K] [--sph-reflective K] [--obj lighthouse.obj] [--rows Y0 Y1]\n"
+          "   [--tri-reflective K] [--sph-reflective K] [--obj lighthouse.obj | --tris-f32 F] [--rows Y0 Y1]\n"
           "   [--stock] [--dump-scene F] [--out-f64 F] [--out-rgb F] [--out-ppm F] [--no-render]\n"
           "rt_ref_capture --capture --scene refraction|world_with_plane|dual_spheres|cube|spheres ... (same options)\n");
   exit(2);
@@ -398,6 +413,7 @@ int rt_harness_main(int argc, char** argv) {
 int main(int argc, char** argv) {
 #endif
   const char* obj = "lighthouse.obj";
+  const char* tris_f32 = NULL;
   memset(&g_opt, 0, sizeof g_opt);
   g_opt.W = HORIZONTAL_SIZE; g_opt.H = VERTICAL_SIZE; g_opt.G = 1; g_opt.y1 = -1;
   int capture = 0;
@@ -408,6 +424,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--tri-reflective") && i + 1 < argc) g_opt.tri_refl = atof(argv[++i]);
     else if (!strcmp(argv[i], "--sph-reflective") && i + 1 < argc) g_opt.sph_refl = atof(argv[++i]);
     else if (!strcmp(argv[i], "--obj") && i + 1 < argc) obj = argv[++i];
+    else if (!strcmp(argv[i], "--tris-f32") && i + 1 < argc) tris_f32 = argv[++i];
     else if (!strcmp(argv[i], "--rows") && i + 2 < argc) { g_opt.y0 = atoi(argv[++i]); g_opt.y1 = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "--stock")) g_opt.stock = 1;
     else if (!strcmp(argv[i], "--capture")) capture = 1;
@@ -471,7 +488,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   scene_t s;
-  if (!strcmp(scene, "lighthouse")) s = scene_lighthouse(W, H, obj);
+  if (!strcmp(scene, "lighthouse")) s = scene_lighthouse(W, H, obj, tris_f32);
   else if (!strcmp(scene, "cube")) s = scene_cube(W, H);
   else if (!strcmp(scene, "spheres")) s = scene_spheres(W, H);
   else if (!strcmp(scene, "cube_spheres")) s = scene_cube_spheres(W, H);

@@ -4,7 +4,7 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
- *                 [--host-ppm] [--reference-list] [--device-bvh] [--gpus N] [--frames K] [--json]
+ *                 [--host-ppm] [--reference-list] [--device-bvh] [--gpus N] [--frames K] [--json] [--no-count]
  *
  * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres, refraction,
  * world_with_plane, dual_spheres.
@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
   const char* obj = "lighthouse.obj";
   const char* tris_f32 = NULL;
   const char* out = "canvas.ppm";
-  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0, gpus = -1, frames = 1, json = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
+  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0, gpus = -1, frames = 1, json = 0, count = 1; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
   double tri_refl = 0.0, sph_refl = 0.0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--json")) json = 1;
+    else if (!strcmp(argv[i], "--no-count")) count = 0; /* the production kernel from the first call on (no ray counters) */
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -90,14 +91,18 @@ int main(int argc, char** argv) {
 
   const int multi = gpus >= 0;
   if (frames < 1) frames = 1;
+  double t_init = now_s(), init_ms = 0.0, upload_ms = 0.0;
   if (multi) {
     host_ppm = 1; /* the gathered image comes back as 8-bit rows; the C writer emits the file */
     if ((rc = rt_hip_multi_init(gpus)) != RT_OK) return fail("rt_hip_multi_init", rc);
+    init_ms = (now_s() - t_init) * 1e3;
     if ((rc = rt_hip_multi_upload_scene(&s)) != RT_OK) return fail("rt_hip_multi_upload_scene", rc);
   } else {
     if ((rc = rt_hip_init(device)) != RT_OK) return fail("rt_hip_init", rc);
+    init_ms = (now_s() - t_init) * 1e3;
     if ((rc = rt_hip_upload_scene(&s)) != RT_OK) return fail("rt_hip_upload_scene", rc);
   }
+  upload_ms = (now_s() - t_init) * 1e3 - init_ms;
   if (device_bvh && !multi) {
     rt_bvh_device_info info;
     if ((rc = rt_hip_build_bvh_device(4, &info)) != RT_OK) return fail("rt_hip_build_bvh_device", rc);
@@ -108,7 +113,7 @@ int main(int argc, char** argv) {
   uint8_t* buf = malloc(cap ? cap : 1); /* the 8-bit image, or the text of the file */
   if (!buf) return 1;
   size_t text_len = 0;
-  rt_render_params p = {5 /* RECURSION_DEPTH */, G, accel, 1, 1, 1, 0, 0};
+  rt_render_params p = {5 /* RECURSION_DEPTH */, G, accel, count, 1, 1, 0, 0};
   rt_stats st;
   printf("Starting Render Process\n");
   double t0 = now_s();
@@ -148,8 +153,10 @@ int main(int argc, char** argv) {
   }
   if (json)
     printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"gpus\": %d, \"rays\": %llu, "
-           "\"first_call_ms\": %.4f, \"frames\": %d, \"ms_per_frame\": %.5f, \"kernel_ms\": %.5f, \"exchange_ms\": %.5f}\n",
-           scene, W, H, G, multi ? rt_hip_multi_devices() : 1, rays, dt * 1e3, frames, per_frame_ms, kernel_ms, exchange_ms);
+           "\"init_ms\": %.3f, \"upload_ms\": %.3f, \"first_call_ms\": %.4f, \"first_call_kernel_ms\": %.4f, \"frames\": %d, "
+           "\"ms_per_frame\": %.5f, \"kernel_ms\": %.5f, \"exchange_ms\": %.5f}\n",
+           scene, W, H, G, multi ? rt_hip_multi_devices() : 1, rays, init_ms, upload_ms, dt * 1e3, st.kernel_ms, frames, per_frame_ms,
+           kernel_ms, exchange_ms);
   printf("Writing Canvas To File\n");
   if (host_ppm) {
     if ((rc = rt_write_ppm(out, buf, W, H)) != RT_OK) return fail("rt_write_ppm", rc);

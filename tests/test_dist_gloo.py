@@ -117,3 +117,54 @@ def test_band_helpers():
     assert default_band_rows(20, 8) >= 1
     ys = [rank_rows(50, 4, 3, r) for r in range(3)]
     assert sorted(np.concatenate(ys).tolist()) == list(range(50))
+
+
+def _bench_loop_worker(rank, world, port, n_frames, out_dir):
+    """bench.py's own run_frames() loop (the timed region of `bench.py --gpus N`), with the CPU oracle as the
+    renderer and gloo as the transport: every frame must end up complete on exactly one rank."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import oracle_lib as O
+    import raytracer_amd as R
+    from raytracer_amd.dist import FrameExchange, default_band_rows
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 45, 37
+    scene = R.stock_scene("cube", W, H)
+    band_rows = default_band_rows(H, world)
+    fx = FrameExchange(H, W, band_rows, world, rank, torch.device("cpu"), rounds=2, slots=2)
+    part, _ = O.render_rgb(scene, n_ranks=world, band_rows=band_rows, rank=rank)
+    part = torch.from_numpy(part)
+    seen = []
+
+    def render(target):
+        target[: fx.n_local] = part
+
+    real_finish = fx.finish
+
+    def finish(handle, slot=0):
+        frames = real_finish(handle, slot)
+        seen.extend(img.numpy().copy() for _, img in frames)
+        return frames
+
+    fx.finish = finish
+    held = bench.run_frames(render, fx, n_frames)
+    assert held == len(seen)
+    full, _ = O.render_rgb(scene)
+    for img in seen:
+        assert np.array_equal(img, full)
+    count = torch.tensor([held], dtype=torch.int64)
+    dist.all_reduce(count)
+    if rank == 0:
+        with open(os.path.join(out_dir, "held.txt"), "w") as fh:
+            fh.write(str(int(count.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 11), (3, 7)])
+def test_bench_run_frames_loop_over_gloo(tmp_path, world, n_frames):
+    mp.spawn(_bench_loop_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    assert int(open(tmp_path / "held.txt").read()) == n_frames
