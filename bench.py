@@ -238,6 +238,34 @@ def ppm_measurements(hip, dev, steps=50):
     return out
 
 
+def ppm_to_host_measurements(hip, frames=60):
+    """render() + write_canvas_to_file()'s text, into host memory, per 1080p frame of the headline scene: one
+    synchronous call per frame (rt_hip_render_ppm, pageable buffer) against two frames in flight
+    (rt_hip_render_ppm_submit / _collect: pinned buffers, the copy of frame f beside the rendering of f + 1)."""
+    import numpy as np
+
+    hip.upload(R.stock_scene(SCENE, WIDTH, HEIGHT))
+    text, _ = hip.render_ppm()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        hip.render_ppm()
+    sync_ms = (time.perf_counter() - t0) / 10 * 1e3
+    p = R.make_params()
+    hip.render_ppm_submit(0, p)
+    for f in range(1, 4):
+        hip.render_ppm_submit(f % 2, p)
+        hip.render_ppm_collect((f - 1) % 2, copy=False)
+    t0 = time.perf_counter()
+    for f in range(4, 4 + frames):
+        hip.render_ppm_submit(f % 2, p)
+        hip.render_ppm_collect((f - 1) % 2, copy=False)
+    piped_ms = (time.perf_counter() - t0) / frames * 1e3
+    last, _ = hip.render_ppm_collect((4 + frames - 1) % 2)
+    return {"frame": f"{SCENE} {WIDTH}x{HEIGHT}", "text_bytes": len(text), "synchronous_ms_per_frame": round(sync_ms, 4),
+            "two_in_flight_ms_per_frame": round(piped_ms, 4), "host_link_gb_s": round(len(text) / piped_ms / 1e6, 1),
+            "bytes_identical": last == text}
+
+
 def run_json(cmd, timeout, cwd=None):
     """Run a child process whose last stdout line starting with '{' is JSON; (dict or None, wall seconds, error text)."""
     t0 = time.perf_counter()
@@ -527,6 +555,7 @@ def main():
             line["general_kernel_scenes"] = general_measurements(hip, dev)
             line["frames_pipelined_over_streams"] = pipelined_measurements(hip, dev)
             line["ppm_text_on_device_random_image"] = ppm_measurements(hip, dev)
+            line["ppm_text_to_host_memory"] = ppm_to_host_measurements(hip)
     if world > 1 and not a.no_side:
         # What a single render() call over N GPUs costs (one gather to rank 0 per frame), for the headline frame and
         # for the two configurations the row-band design is for.  Every rank takes part; rank 0 reports.

@@ -346,6 +346,17 @@ size_t rt_hip_gather_offset(int hsize, int vsize, int band_rows, int n_ranks, in
 int rt_hip_place_bands_device(const void* gathered_device, void* rgb_out_device, int hsize, int vsize, int band_rows,
                               int n_ranks, void* stream);
 
+/* The same for a run of frames, two in flight: rt_hip_render_ppm_submit(params, slot) enqueues render + formatting
+ * of a frame into slot 0 or 1 and returns at once; rt_hip_render_ppm_collect(slot, ...) waits for that frame,
+ * copies exactly the bytes of its text to pinned host memory owned by the library (on a copy stream of its own)
+ * and hands out the pointer, valid until the slot is submitted again.  Submit frame f + 1 to the other slot before
+ * collecting frame f and the copy of f overlaps the rendering of f + 1: write_canvas_to_file()'s bytes
+ * (RayTracer.c:1333-1348) at the rate of the host link instead of one synchronous frame at a time.
+ * RT_ERR_NOT_READY: the slot still holds an uncollected frame (submit) / holds none (collect).  stats: kernel time
+ * and kernel choice of that frame; ray counters only through rt_hip_render_ppm. */
+int rt_hip_render_ppm_submit(const rt_render_params* params, int slot);
+int rt_hip_render_ppm_collect(int slot, const char** text_host, size_t* bytes_out, rt_stats* stats);
+
 /* Number of image rows that belong to `rank` (see rt_render_params). */
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank);
 

@@ -78,14 +78,16 @@ int rt_scene_add_triangle_ext(rt_scene_builder* b, const double p1[3], const dou
                               const rt_material* m, const rt_material_ext* x, const double* pattern_transform);
 /* n triangles, 9 floats each (p1 p2 p3), widened to double as load_model_file does (RayTracer.c:1657-1669) */
 int rt_scene_add_triangles_f32(rt_scene_builder* b, const float* xyz9, int n, const rt_material* m);
-/* `v` and `f` records of a Wavefront OBJ text; 3- or 4-vertex faces (quads fan-split, RayTracer.c:1696-1697) */
+/* `v` and `f` records of a Wavefront OBJ text (`len` bytes, no terminator needed); 3- or 4-vertex faces (quads
+ * fan-split, RayTracer.c:1696-1697).  Face indices are 1-based and refer to vertices already read, as in the
+ * reference's files; relative (negative) indices are refused with RT_ERR_INVALID. */
 int rt_scene_load_obj(rt_scene_builder* b, const char* text, size_t len, const rt_material* m);
 int rt_scene_load_obj_file(rt_scene_builder* b, const char* path, const rt_material* m);
 
 /* override material.reflective of every triangle / every sphere added so far */
 int rt_scene_set_reflective(rt_scene_builder* b, double tri_reflective, double sph_reflective);
 
-/* Derive inverses, build the BVH (leaf_size <= 0: no BVH) and fill *out.  The
+/* Derive inverses, build the BVH (leaf_size <= 0: no BVH; at most 7, RT_ERR_TOO_LARGE beyond) and fill *out.  The
  * arrays *out points at belong to the builder and live until
  * rt_scene_destroy / the next rt_scene_finish. */
 int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out);

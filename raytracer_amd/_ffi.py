@@ -245,6 +245,8 @@ def hip_lib():
         L.rt_hip_format_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_hip_render_ppm.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                         C.POINTER(Stats)]
+        L.rt_hip_render_ppm_submit.argtypes = [C.POINTER(RenderParams), C.c_int]
+        L.rt_hip_render_ppm_collect.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
         L.rt_hip_shutdown.restype = None
         L.rt_hip_strerror.argtypes = [C.c_int]
         L.rt_hip_strerror.restype = C.c_char_p
@@ -267,6 +269,8 @@ HIP_EXPORTS = [
     "rt_hip_format_ppm_device_noalloc",
     "rt_hip_format_ppm",
     "rt_hip_render_ppm",
+    "rt_hip_render_ppm_submit",
+    "rt_hip_render_ppm_collect",
     "rt_hip_device_count",
     "rt_hip_multi_init",
     "rt_hip_multi_devices",

@@ -33,12 +33,19 @@ static __device__ __align__(256) unsigned ppm_scratch[2 * (kNoAllocMaxChunks + 1
 
 namespace {
 
+/* What render_enqueue launched, for render_collect. */
+struct Enqueued {
+  int rows = 0;
+  int accel_used = RT_ACCEL_BRUTE;
+  bool timed = false, count = false;
+};
+
 struct Context {
   bool ready = false;
   bool have_scene = false;
   int device = -1;
   int n_cu = 256;
-  int light_per_block = 4; /* background-only tiles per workgroup */
+  int light_per_block = 20; /* background-only tiles per workgroup (filled five at a time) */
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
   bool lds_stack = true;
@@ -71,6 +78,7 @@ struct Context {
     int32_t* d_list = nullptr;
     size_t cap = 0;
     int heavy = 0, tiles = 0, entries = 0;
+    bool light_background = false; /* the light tiles lie outside the mesh's pixel rectangle */
     unsigned long long last_use = 0;
   };
   static constexpr int kPlans = 4;
@@ -103,6 +111,22 @@ struct Context {
   hipStream_t ppm_stream = nullptr;          /* stream of the last formatting call */
   bool ppm_pending = false;
   hipEvent_t ppm_ev = nullptr;               /* orders formatting calls on different streams: they share the arrays above */
+  /* rt_hip_render_ppm_submit / _collect: two frames in flight, each with its image, its text on the device and in
+   * pinned host memory, its length word and its event; the text travels on a stream of its own */
+  struct PpmSlot {
+    unsigned char* d_rgb = nullptr;
+    unsigned char* d_text = nullptr;
+    char* h_text = nullptr;                  /* pinned */
+    unsigned long long* h_len = nullptr;     /* pinned */
+    unsigned long long* d_len = nullptr;     /* the same word as the device addresses it */
+    size_t rgb_bytes = 0, text_bytes = 0;
+    hipEvent_t formatted = nullptr;
+    bool busy = false;
+    Enqueued enq;
+    hipEvent_t k0 = nullptr, k1 = nullptr;   /* around the trace kernel, for rt_stats */
+  };
+  PpmSlot ppm_slot[2];
+  hipStream_t copy_stream = nullptr;
   unsigned* ppm_scratch_ptr = nullptr;       /* this device's copy of ppm_scratch */
   hipStream_t noalloc_stream = nullptr;      /* stream of the last rt_hip_format_ppm_device_noalloc call */
   bool noalloc_pending = false;
@@ -354,6 +378,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.n_heavy = n_tiles;
   a.light_per_block = 1;
   a.n_entries = 0;
+  a.light_is_background = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
   /* with spheres in the world any pixel may be expensive; without triangles there is nothing to sort by */
@@ -484,6 +509,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     }
     plan->heavy = (int)heavy.size();
     plan->tiles = n_tiles;
+    plan->light_background = have_rect && !light.empty();
     heavy.insert(heavy.end(), light.begin(), light.end());
     plan->entries = (int)heavy.size();
     const int src = store_plan(plan, key, heavy, s);
@@ -493,6 +519,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.n_heavy = plan->heavy;
   a.light_per_block = cur->light_per_block;
   a.n_entries = plan->entries;
+  a.light_is_background = plan->light_background ? 1 : 0;
   n_blocks = plan->heavy + (plan->entries - plan->heavy + cur->light_per_block - 1) / cur->light_per_block;
   return RT_OK;
 }
@@ -772,13 +799,6 @@ int check_params(const rt_render_params* p) {
   return RT_OK;
 }
 
-/* What render_enqueue launched, for render_collect. */
-struct Enqueued {
-  int rows = 0;
-  int accel_used = RT_ACCEL_BRUTE;
-  bool timed = false, count = false;
-};
-
 /* Enqueue one render of the current context's scene on `s` and return at once.  timed: record the context's
  * event pair around the kernel; count: the counting build, counters zeroed first. */
 int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, bool timed, bool count,
@@ -810,6 +830,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
       a.light_per_block = 1;
       a.ablate = 0; /* the timing cuts are the fast kernels'; this kernel reads the field as "probe launch" */
       a.n_entries = 0;
+      a.light_is_background = 0;
       n_blocks = (int)n_tiles;
       bvh = false;
       const int prc = plan_general_tiles(p, rows, s, a);
@@ -912,6 +933,48 @@ int warm_launch() {
   std::vector<unsigned char> sink(probe ? probe : 1);
   if (probe) HIP_TRY(hipMemcpyAsync(sink.data(), cur->d_rgb, probe, hipMemcpyDeviceToHost, cur->stream));
   HIP_TRY(hipStreamSynchronize(cur->stream));
+  return RT_OK;
+}
+
+/* The two formatting launches on `s`: text lengths of the chunks and groups, then the text.  chunk_len / group_len:
+ * at least n_chunks + 1 words each; total_out: where the kernel stores the length of the file (device memory or the
+ * device address of pinned host memory).  An empty image is one workgroup that finds no pixels and writes the
+ * header and the length. */
+int ppm_enqueue(const void* rgb_device, int width, int height, void* text_device, unsigned* chunk_len, unsigned* group_len,
+                unsigned long long* total_out, hipStream_t s) {
+  const long long n_px = (long long)width * height;
+  const int n_chunks = (int)((n_px + PPM_CHUNK - 1) / PPM_CHUNK);
+  PpmHeader hd;
+  memset(&hd, 0, sizeof hd);
+  hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
+  /* groups: about a thousand of them keep both the length pass parallel and a chunk's sum over groups short */
+  int per_group = n_chunks / 1024;
+  per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
+  const int n_groups = (n_chunks + per_group - 1) / per_group;
+  if (n_chunks > 0)
+    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s, (const unsigned char*)rgb_device, n_px,
+                       n_chunks, per_group, chunk_len, group_len);
+  hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)(n_chunks > 0 ? n_chunks : 1)), dim3(PPM_THREADS), 0, s,
+                     (const unsigned char*)rgb_device, n_px, (const unsigned*)chunk_len, (const unsigned*)group_len, per_group, hd,
+                     (unsigned char*)text_device, total_out);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+/* room for n_chunks + 1 words in each of the library-owned length arrays (every formatting call on this context
+ * shares them; calls are ordered by stream or by ppm_ev) */
+int ppm_reserve(int n_chunks) {
+  if ((size_t)n_chunks + 1 <= cur->ppm_chunks_cap) return RT_OK;
+  if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream));
+  HIP_TRY(hipStreamSynchronize(cur->stream));
+  if (cur->d_ppm_len) (void)hipFree(cur->d_ppm_len);
+  if (cur->d_ppm_group) (void)hipFree(cur->d_ppm_group);
+  cur->d_ppm_len = nullptr;
+  cur->d_ppm_group = nullptr;
+  cur->ppm_chunks_cap = 0;
+  HIP_TRY(hipMalloc((void**)&cur->d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
+  HIP_TRY(hipMalloc((void**)&cur->d_ppm_group, sizeof(unsigned) * ((size_t)n_chunks + 1)));
+  cur->ppm_chunks_cap = (size_t)n_chunks + 1;
   return RT_OK;
 }
 
@@ -1034,7 +1097,7 @@ int create_context(int device) {
   HIP_TRY(hipEventCreate(&cur->tm0));
   HIP_TRY(hipEventCreate(&cur->tm1));
   HIP_TRY(hipEventCreateWithFlags(&cur->ppm_ev, hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void**)&cur->d_counters, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&cur->d_counters, (16 + (RT_STAMPS ? 6 * (size_t)RT_STAMPS_MAX_WAVES : 0)) * sizeof(unsigned long long)));
   HIP_TRY(hipGetSymbolAddress((void**)&cur->ppm_scratch_ptr, HIP_SYMBOL(ppm_scratch)));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -1083,6 +1146,16 @@ void destroy_context(Context* c) {
   if (c->tm0) (void)hipEventDestroy(c->tm0);
   if (c->tm1) (void)hipEventDestroy(c->tm1);
   if (c->ppm_ev) (void)hipEventDestroy(c->ppm_ev);
+  for (Context::PpmSlot& q : c->ppm_slot) {
+    if (q.d_rgb) (void)hipFree(q.d_rgb);
+    if (q.d_text) (void)hipFree(q.d_text);
+    if (q.h_text) (void)hipHostFree(q.h_text);
+    if (q.h_len) (void)hipHostFree(q.h_len);
+    if (q.formatted) (void)hipEventDestroy(q.formatted);
+    if (q.k0) (void)hipEventDestroy(q.k0);
+    if (q.k1) (void)hipEventDestroy(q.k1);
+  }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   *c = Context{};
 }
@@ -1523,53 +1596,24 @@ int rt_hip_format_ppm_device(const void* rgb_device, int width, int height, void
   if ((reinterpret_cast<uintptr_t>(rgb_device) & 3u) != 0 || (reinterpret_cast<uintptr_t>(text_device) & 15u) != 0)
     return RT_ERR_INVALID;
   if (capacity < rt_hip_ppm_capacity(width, height)) return RT_ERR_TOO_LARGE;
-  const long long n_px = (long long)width * height;
-  const long long n_chunks_ll = (n_px + PPM_CHUNK - 1) / PPM_CHUNK;
+  const long long n_chunks_ll = ((long long)width * height + PPM_CHUNK - 1) / PPM_CHUNK;
   if (n_chunks_ll > (1ll << 30)) return RT_ERR_TOO_LARGE;
-  const int n_chunks = (int)n_chunks_ll;
   hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
-  PpmHeader hd;
-  memset(&hd, 0, sizeof hd);
-  hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
   if (!cur->h_ppm_total) {
     HIP_TRY(hipHostMalloc((void**)&cur->h_ppm_total, sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**)&cur->d_ppm_total_host, cur->h_ppm_total, 0));
   }
-  /* groups: about a thousand of them keep both the length pass parallel and a chunk's sum over groups short */
-  int per_group = n_chunks / 1024;
-  per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
-  const int n_groups = (n_chunks + per_group - 1) / per_group;
-  if ((size_t)n_chunks + 1 > cur->ppm_chunks_cap) {
-    if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream));
-    if (cur->d_ppm_len) (void)hipFree(cur->d_ppm_len);
-    if (cur->d_ppm_group) (void)hipFree(cur->d_ppm_group);
-    cur->d_ppm_len = nullptr;
-    cur->d_ppm_group = nullptr;
-    cur->ppm_chunks_cap = 0;
-    HIP_TRY(hipMalloc((void**)&cur->d_ppm_len, sizeof(unsigned) * ((size_t)n_chunks + 1)));
-    HIP_TRY(hipMalloc((void**)&cur->d_ppm_group, sizeof(unsigned) * ((size_t)n_chunks + 1)));
-    cur->ppm_chunks_cap = (size_t)n_chunks + 1;
-  }
+  int rc = ppm_reserve((int)n_chunks_ll);
+  if (rc != RT_OK) return rc;
   /* every call shares the length arrays and the pinned length word: a call on another stream than the last one
    * starts after that one has finished */
   if (cur->ppm_pending && cur->ppm_stream != s) {
     HIP_TRY(hipEventRecord(cur->ppm_ev, cur->ppm_stream));
     HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
   }
-  if (n_chunks > 0) {
-    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, n_chunks, per_group, cur->d_ppm_len, cur->d_ppm_group);
-    hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)n_chunks), dim3(PPM_THREADS), 0, s,
-                       (const unsigned char*)rgb_device, n_px, (const unsigned*)cur->d_ppm_len, (const unsigned*)cur->d_ppm_group,
-                       per_group, hd, (unsigned char*)text_device, cur->d_ppm_total_host);
-  } else {
-    if (cur->ppm_pending) HIP_TRY(hipStreamSynchronize(cur->ppm_stream)); /* nobody else is writing the length word */
-    HIP_TRY(hipMemcpyAsync(text_device, hd.text, (size_t)hd.len, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); /* hd lives on this stack frame */
-    *cur->h_ppm_total = (unsigned long long)hd.len;
-  }
-  HIP_TRY(hipGetLastError());
-  cur->ppm_stream = s; /* the scan kernel has put the length into *h_ppm_total once the stream has drained */
+  if ((rc = ppm_enqueue(rgb_device, width, height, text_device, cur->d_ppm_len, cur->d_ppm_group, cur->d_ppm_total_host, s)) != RT_OK)
+    return rc;
+  cur->ppm_stream = s; /* the write kernel has put the length into *h_ppm_total once the stream has drained */
   cur->ppm_pending = true;
   if (bytes_out) return rt_hip_ppm_last_length(bytes_out);
   return RT_OK;
@@ -1601,14 +1645,7 @@ int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int heig
              (long long)kNoAllocMaxChunks * PPM_CHUNK);
     return RT_ERR_TOO_LARGE;
   }
-  const int n_chunks = (int)n_chunks_ll;
   hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
-  PpmHeader hd;
-  memset(&hd, 0, sizeof hd);
-  hd.len = snprintf(hd.text, sizeof hd.text, "P3\n%d %d\n255\n", width, height); /* RayTracer.c:1335-1336 */
-  int per_group = n_chunks / 1024;
-  per_group = per_group < 1 ? 1 : (per_group > PPM_MAX_GROUP ? PPM_MAX_GROUP : per_group);
-  const int n_groups = (n_chunks + per_group - 1) / per_group;
   unsigned* const chunk_len = cur->ppm_scratch_ptr;
   unsigned* const group_len = cur->ppm_scratch_ptr + (kNoAllocMaxChunks + 1);
   /* the scratch is one per GPU: a call on another stream than the last one starts after that one has finished.
@@ -1617,14 +1654,8 @@ int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int heig
     HIP_TRY(hipEventRecord(cur->ppm_ev, cur->noalloc_stream));
     HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
   }
-  if (n_chunks > 0)
-    hipLaunchKernelGGL(ppm_len_kernel, dim3((unsigned)n_groups), dim3(PPM_THREADS), 0, s, (const unsigned char*)rgb_device, n_px,
-                       n_chunks, per_group, chunk_len, group_len);
-  /* an empty image: one workgroup that finds no pixels writes the header and the length */
-  hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)(n_chunks > 0 ? n_chunks : 1)), dim3(PPM_THREADS), 0, s,
-                     (const unsigned char*)rgb_device, n_px, (const unsigned*)chunk_len, (const unsigned*)group_len, per_group, hd,
-                     (unsigned char*)text_device, length_device);
-  HIP_TRY(hipGetLastError());
+  const int erc = ppm_enqueue(rgb_device, width, height, text_device, chunk_len, group_len, length_device, s);
+  if (erc != RT_OK) return erc;
   cur->noalloc_stream = s;
   cur->noalloc_pending = true;
   return RT_OK;
@@ -1668,6 +1699,93 @@ int rt_hip_render_ppm(const rt_render_params* p, char* text_host, size_t capacit
   rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats);
   if (rc != RT_OK) return rc;
   return rt_hip_format_ppm(cur->d_rgb, cur->scene.hsize, cur->scene.vsize, text_host, capacity, bytes_out);
+}
+
+int rt_hip_render_ppm_submit(const rt_render_params* p, int slot) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  if (p->n_ranks != 1) return RT_ERR_INVALID; /* the file is one whole frame */
+  if (slot < 0 || slot > 1) return RT_ERR_INVALID;
+  Context::PpmSlot& q = cur->ppm_slot[slot];
+  if (q.busy) return RT_ERR_NOT_READY; /* collect the slot's previous frame first */
+  const int W = cur->scene.hsize, H = cur->scene.vsize;
+  const size_t bytes = (size_t)W * H * 3, cap = rt_hip_ppm_capacity(W, H);
+  if (!cur->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&cur->copy_stream, hipStreamNonBlocking));
+  if (!q.formatted) {
+    HIP_TRY(hipEventCreateWithFlags(&q.formatted, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&q.k0));
+    HIP_TRY(hipEventCreate(&q.k1));
+    HIP_TRY(hipHostMalloc((void**)&q.h_len, sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&q.d_len, q.h_len, 0));
+  }
+  if (bytes > q.rgb_bytes) {
+    if (q.d_rgb) (void)hipFree(q.d_rgb);
+    q.d_rgb = nullptr;
+    q.rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&q.d_rgb, bytes ? bytes : 16));
+    q.rgb_bytes = bytes;
+  }
+  if (cap > q.text_bytes) {
+    if (q.d_text) (void)hipFree(q.d_text);
+    if (q.h_text) (void)hipHostFree(q.h_text);
+    q.d_text = nullptr;
+    q.h_text = nullptr;
+    q.text_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&q.d_text, cap));
+    HIP_TRY(hipHostMalloc((void**)&q.h_text, cap, hipHostMallocDefault));
+    q.text_bytes = cap;
+  }
+  const long long n_chunks_ll = ((long long)W * H + PPM_CHUNK - 1) / PPM_CHUNK;
+  if (n_chunks_ll > (1ll << 30)) return RT_ERR_TOO_LARGE;
+  if ((rc = ppm_reserve((int)n_chunks_ll)) != RT_OK) return rc;
+  hipStream_t s = cur->stream;
+  if (cur->ppm_pending && cur->ppm_stream != s) { /* a formatting call of the caller's on another stream shares the length arrays */
+    HIP_TRY(hipEventRecord(cur->ppm_ev, cur->ppm_stream));
+    HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
+  }
+  /* render and format on the library's stream; the kernel time goes to the slot's own event pair */
+  hipEvent_t keep0 = cur->ev0, keep1 = cur->ev1;
+  cur->ev0 = q.k0;
+  cur->ev1 = q.k1;
+  rc = render_enqueue(p, q.d_rgb, nullptr, s, true, p->count_rays != 0, &q.enq);
+  cur->ev0 = keep0;
+  cur->ev1 = keep1;
+  if (rc != RT_OK) return rc;
+  if ((rc = ppm_enqueue(q.d_rgb, W, H, q.d_text, cur->d_ppm_len, cur->d_ppm_group, q.d_len, s)) != RT_OK) return rc;
+  HIP_TRY(hipEventRecord(q.formatted, s));
+  cur->ppm_stream = s;
+  cur->ppm_pending = true;
+  q.busy = true;
+  return RT_OK;
+}
+
+int rt_hip_render_ppm_collect(int slot, const char** text_host, size_t* bytes_out, rt_stats* stats) {
+  if (!cur->ready) return RT_ERR_NOT_READY;
+  if (slot < 0 || slot > 1 || !text_host || !bytes_out) return RT_ERR_INVALID;
+  Context::PpmSlot& q = cur->ppm_slot[slot];
+  if (!q.busy) return RT_ERR_NOT_READY;
+  /* the length is known once the frame is formatted; only then can the copy of exactly that many bytes be issued.
+   * It runs on the copy stream, beside whatever the caller has submitted to the other slot meanwhile. */
+  HIP_TRY(hipEventSynchronize(q.formatted));
+  const size_t len = (size_t)*q.h_len;
+  if (len > q.text_bytes) return RT_ERR_HIP;
+  if (len) HIP_TRY(hipMemcpyAsync(q.h_text, q.d_text, len, hipMemcpyDeviceToHost, cur->copy_stream));
+  HIP_TRY(hipStreamSynchronize(cur->copy_stream));
+  q.busy = false;
+  *text_host = q.h_text;
+  *bytes_out = len;
+  if (stats) {
+    hipEvent_t keep0 = cur->ev0, keep1 = cur->ev1;
+    cur->ev0 = q.k0;
+    cur->ev1 = q.k1;
+    Enqueued e = q.enq;
+    if (e.count) e.count = false; /* the counters belong to the context and a later frame may have reset them */
+    const int rc = render_collect(e, cur->stream, stats);
+    cur->ev0 = keep0;
+    cur->ev1 = keep1;
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
 }
 
 int rt_hip_rank_rows(int vsize, int band_rows, int n_ranks, int rank) {
@@ -1889,6 +2007,16 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
   }
   return RT_OK;
 }
+
+#if RT_STAMPS
+/* development builds: the per-wave time stamps of the last launch (6 words per wave) */
+int rt_hip_debug_stamps(unsigned long long* out, int n_waves) {
+  if (!cur->ready || n_waves < 0 || n_waves > RT_STAMPS_MAX_WAVES) return RT_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(cur->stream));
+  HIP_TRY(hipMemcpy(out, cur->d_counters + 16, sizeof(unsigned long long) * 6 * (size_t)n_waves, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+#endif
 
 int rt_hip_multi_devices(void) { return g_multi_n; }
 

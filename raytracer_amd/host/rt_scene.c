@@ -397,8 +397,13 @@ int rt_scene_load_obj(rt_scene_builder* b, const char* text, size_t len, const r
       while (p < e && n < 4) {
         while (p < e && (text[p] == ' ' || text[p] == '\t')) ++p;
         if (p >= e || text[p] == '\r') break;
-        idx[n++] = atoi(text + p); /* leading integer of v, v/vt, v//vn or v/vt/vn */
-        while (p < e && text[p] != ' ' && text[p] != '\t') ++p;
+        /* leading integer of v, v/vt, v//vn or v/vt/vn, read inside the line (the buffer need not be terminated) */
+        size_t q = p;
+        while (q < e && text[q] != ' ' && text[q] != '\t' && text[q] != '\r') ++q;
+        size_t nt = q - p < sizeof tok - 1 ? q - p : sizeof tok - 1;
+        memcpy(tok, text + p, nt); tok[nt] = 0;
+        idx[n++] = atoi(tok);
+        p = q;
       }
       if (n < 3) { rc = RT_ERR_UNSUPPORTED; break; }
       for (int k = 0; k < n; ++k)
@@ -424,9 +429,9 @@ int rt_scene_load_obj_file(rt_scene_builder* b, const char* path, const rt_mater
   if (!b || !path) return RT_ERR_INVALID;
   FILE* f = fopen(path, "rb");
   if (!f) return RT_ERR_INVALID;
-  fseek(f, 0, SEEK_END);
-  long n = ftell(f);
-  rewind(f);
+  long n = -1;
+  if (fseek(f, 0, SEEK_END) == 0) n = ftell(f);
+  if (n < 0 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return RT_ERR_INVALID; }
   char* buf = malloc((size_t)n + 1);
   if (!buf) { fclose(f); return RT_ERR_INVALID; }
   size_t got = fread(buf, 1, (size_t)n, f);
@@ -441,6 +446,7 @@ int rt_scene_load_obj_file(rt_scene_builder* b, const char* path, const rt_mater
 int rt_scene_finish(rt_scene_builder* b, int bvh_leaf_size, rt_scene* out) {
   if (!b || !out) return RT_ERR_INVALID;
   if (!b->have_camera || !b->have_light) return RT_ERR_NOT_READY;
+  if (bvh_leaf_size > 7) return RT_ERR_TOO_LARGE; /* the device's leaf encoding holds up to 7 triangles */
   free_outputs(b);
   memset(out, 0, sizeof *out);
   const int ns = b->n_spheres, nt = b->n_tris;

@@ -137,6 +137,17 @@ class HipRenderer:
         _check(self._L.rt_hip_place_bands_device(C.c_void_p(gathered_ptr), C.c_void_p(out_ptr), width, height, band_rows,
                                                  n_ranks, C.c_void_p(stream or 0)), "rt_hip_place_bands_device")
 
+    def render_ppm_submit(self, slot, params=None, **kw):
+        """Enqueue render + formatting of a frame into slot 0 or 1 (returns at once)."""
+        p = params or make_params(**kw)
+        _check(self._L.rt_hip_render_ppm_submit(C.byref(p), int(slot)), "rt_hip_render_ppm_submit")
+
+    def render_ppm_collect(self, slot, copy=True):
+        """Wait for the slot's frame: (bytes of canvas.ppm, stats); copy=False returns its length only (timing)."""
+        ptr, n, st = C.c_void_p(), C.c_size_t(0), Stats()
+        _check(self._L.rt_hip_render_ppm_collect(int(slot), C.byref(ptr), C.byref(n), C.byref(st)), "rt_hip_render_ppm_collect")
+        return (C.string_at(ptr.value, n.value) if copy else n.value), st
+
     def timer_start(self, stream=None):
         _check(self._L.rt_hip_event_record(0, C.c_void_p(stream or 0)), "rt_hip_event_record")
 

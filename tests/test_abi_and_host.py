@@ -137,6 +137,23 @@ def test_obj_reader_matches_reference_loader():
     assert lh.shape == (1336, 9)
 
 
+def test_obj_reader_stays_inside_the_length_it_was_given():
+    """(text, len) need not be terminated: a buffer that goes on with digits right behind the last face index must
+    not leak them into the index; relative indices and an oversized BVH leaf are refused."""
+    obj = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3"
+    raw = obj + b"99999\nf 9 9 9\n"
+    b = R.SceneBuilder()
+    b.set_camera(4, 4, 1.0, (0, 0, -5), (0, 0, 0)).set_light((0, 0, 0), (1, 1, 1))
+    L = _ffi.host_lib()
+    assert L.rt_scene_load_obj(b._b, raw, len(obj), None) == _ffi.RT_OK
+    a = R.scene_arrays(b.finish(0))
+    assert a["tri_soa"].shape == (12, 1)
+    assert np.allclose(a["tri_soa"][0:3, 0] + a["tri_soa"][6:9, 0], [0, 1, 0])  # p3 is vertex 3, not 399999
+    assert L.rt_scene_load_obj(b._b, b"f -3 -2 -1\n", 11, None) == _ffi.RT_ERR_INVALID
+    out = _ffi.Scene()
+    assert L.rt_scene_finish(b._b, 8, C.byref(out)) == _ffi.RT_ERR_TOO_LARGE
+
+
 def test_teapot_h_mesh_is_the_reference_cube(manifest):
     import refdump
     from conftest import GOLDEN

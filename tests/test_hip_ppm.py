@@ -96,3 +96,29 @@ def test_8k_frame_text(hip):
     got = device_text(hip, img)
     assert len(got) == want_len
     assert hashlib.sha256(got).digest() == hashlib.sha256(R.ppm_bytes(img)).digest()
+
+
+def test_pipelined_frames_are_the_synchronous_bytes(hip, manifest):
+    """Two frames in flight (submit f + 1 before collecting f): every frame's text equals rt_hip_render_ppm's, also
+    when the scene changes between submissions and when a slot is misused."""
+    e = manifest["cube_300"]
+    hip.upload(scene_for(e))
+    want, _ = hip.render_ppm()
+    assert hashlib.sha256(want).hexdigest() == e["ppm_sha256"]
+    with pytest.raises(R.RtError):
+        hip.render_ppm_collect(0)  # nothing submitted
+    hip.render_ppm_submit(0)
+    with pytest.raises(R.RtError):
+        hip.render_ppm_submit(0)  # still holds a frame
+    for f in range(1, 6):
+        hip.render_ppm_submit(f % 2)
+        got, st = hip.render_ppm_collect((f - 1) % 2)
+        assert got == want and st.kernel_ms > 0
+    got, _ = hip.render_ppm_collect(5 % 2)
+    assert got == want
+    # another scene through the same slots
+    e2 = manifest["spheres_300"]
+    hip.upload(scene_for(e2))
+    hip.render_ppm_submit(0)
+    got, _ = hip.render_ppm_collect(0)
+    assert hashlib.sha256(got).hexdigest() == e2["ppm_sha256"]

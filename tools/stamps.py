@@ -1,0 +1,49 @@
+"""Timeline of one launch from a build with -DRT_STAMPS=1 (make variant TAG=stamps EXTRA_HIPFLAGS=-DRT_STAMPS=1;
+RT_HIP_LIB=stamps): when waves start and end relative to the first start, how long heavy waves run, per-XCD spread."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import raytracer_amd as R
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "cube"
+accel = {"auto": R._ffi.RT_ACCEL_AUTO, "brute": R._ffi.RT_ACCEL_BRUTE, "bvh": R._ffi.RT_ACCEL_BVH}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
+tr = 0.3 if scene.endswith("_refl") else 0.0
+W, H = 1920, 1080
+hip = R.HipRenderer(0)
+L = R._ffi.hip_lib()
+hip.upload(R.stock_scene(scene.replace("_refl", ""), W, H, tr))
+buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+p = R.make_params(accel=accel)
+for _ in range(50):
+    hip.render_device(buf.data_ptr(), p)
+torch.cuda.synchronize()
+NW = 65536
+raw = np.zeros((NW, 6), dtype=np.uint64)
+L.rt_hip_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+assert L.rt_hip_debug_stamps(raw.ctypes.data, NW) == 0
+used = raw[:, 3] > 0
+s = raw[used].astype(np.int64)
+w0, w1 = s[:, 2], s[:, 3]          # 100 MHz wall clock: 10 ns ticks
+t0 = w0.min()
+start_us, end_us = (w0 - t0) / 100.0, (w1 - t0) / 100.0
+dur_us = end_us - start_us
+cyc = (s[:, 1] - s[:, 0])
+heavy = s[:, 5] == 1
+xcc = (s[:, 4] >> 32) & 0xF
+print(f"{scene}: {used.sum()} waves recorded, {heavy.sum()} in heavy workgroups")
+print(f"last wave ends {end_us.max():.2f} us after the first starts; starts: median {np.median(start_us):.2f}, 90% {np.percentile(start_us, 90):.2f}, max {start_us.max():.2f} us")
+for name, m in (("heavy", heavy), ("light", ~heavy)):
+    if m.any():
+        d = dur_us[m]
+        print(f"{name:5s} waves: duration median {np.median(d):.2f} us, 90% {np.percentile(d, 90):.2f}, max {d.max():.2f}; "
+              f"start median {np.median(start_us[m]):.2f}, max {start_us[m].max():.2f}; end max {end_us[m].max():.2f}; "
+              f"shader-clock/wall ratio {np.median(cyc[m] / np.maximum(dur_us[m], 0.01)):.0f} ticks/us")
+print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
+hist, edges = np.histogram(end_us, bins=12)
+print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
+busy = np.zeros(int(end_us.max() * 2) + 2)
+for a_, b_ in zip(start_us, end_us):
+    busy[int(a_ * 2):int(b_ * 2) + 1] += 1
+print("waves in flight per 0.5 us:", [int(x) for x in busy])
+hip.shutdown()
