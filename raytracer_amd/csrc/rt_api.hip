@@ -51,6 +51,7 @@ struct Context {
   bool lds_stack = true;
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
+  int split_refine = 3;    /* launches that measure their waves and split the slowest tiles further */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
@@ -79,6 +80,8 @@ struct Context {
     size_t cap = 0;
     int heavy = 0, tiles = 0, entries = 0;
     bool light_background = false; /* the light tiles lie outside the mesh's pixel rectangle */
+    int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
+    std::vector<int32_t> host_list; /* the list as uploaded, kept while refinements are pending */
     unsigned long long last_use = 0;
   };
   static constexpr int kPlans = 4;
@@ -86,6 +89,8 @@ struct Context {
   unsigned long long plan_clock = 0;
   unsigned long long scene_serial = 0;
   const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
+  TilePlan* launch_plan = nullptr;           /* the plan it came from (plan_tiles), nullptr for an unplanned launch */
+  unsigned long long* launch_counters = nullptr; /* counters argument of the launch being issued (nullptr: d_counters) */
   void* d_tri_primary = nullptr;
   void* d_sph_primary = nullptr;
   unsigned long long* d_counters = nullptr;
@@ -229,7 +234,7 @@ void launch_one(size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsig
                      (const DevSphere*)cur->d_spheres, (const DevSpherePrimary*)cur->d_sph_primary, (const DevTri*)cur->d_tris,
                      (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const rt_material*)cur->d_materials,
                      (const DevBvh2*)cur->d_bvh, (const DevTriF*)cur->d_trif, (const DevSphereF*)cur->d_sphf, a,
-                     cur->launch_tile_list, rgb, canvas, cur->d_counters);
+                     cur->launch_tile_list, rgb, canvas, cur->launch_counters ? cur->launch_counters : cur->d_counters);
 }
 /* kernels specialised for the primitive kinds the scene holds (KIND 1: spheres only, 2: triangles only, 0: both) */
 template <bool BVH, bool REFLECT, int STAGE>
@@ -375,6 +380,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const int n_tiles = tiles_x * tiles_y;
   cur->launch_tile_list = nullptr;
+  cur->launch_plan = nullptr;
   a.n_heavy = n_tiles;
   a.light_per_block = 1;
   a.n_entries = 0;
@@ -500,7 +506,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       for (int32_t tile : heavy) {
         if (cost_of_tile[tile] >= floor_cost) {
           const int parts = cost_of_tile[tile] >= floor_cost4 ? 4 : cur->split_parts;
-          for (int part = 0; part < parts; ++part) split.push_back(tile | (part << 24) | (parts << 26));
+          for (int part = 0; part < parts; ++part) split.push_back(tile | (part << 24) | ((parts == 4 ? 2 : 1) << 28));
         } else {
           split.push_back(tile);
         }
@@ -510,11 +516,20 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     plan->heavy = (int)heavy.size();
     plan->tiles = n_tiles;
     plan->light_background = have_rect && !light.empty();
+    /* the split above goes by how many triangles project into a tile; the first launches with this plan measure
+     * how long every wave really runs and split the slowest further (refine_split) */
+    const bool was_split = bvh && cur->split_parts > 1 && cur->split_tiles > 0 && !cost.empty() &&
+                           !(by_xcd_wanted && heavy.size() >= 64) && n_tiles <= RT_TILE_MASK && !overlap &&
+                           heavy.size() <= (size_t)(cur->split_max_per_cu + 2) * cur->n_cu;
+    plan->refine_left = was_split ? cur->split_refine : 0;
     heavy.insert(heavy.end(), light.begin(), light.end());
     plan->entries = (int)heavy.size();
     const int src = store_plan(plan, key, heavy, s);
     if (src != RT_OK) return src;
+    if (plan->refine_left > 0) plan->host_list = heavy;
+    else plan->host_list.clear();
   }
+  cur->launch_plan = plan;
   cur->launch_tile_list = plan->d_list;
   a.n_heavy = plan->heavy;
   a.light_per_block = cur->light_per_block;
@@ -799,6 +814,125 @@ int check_params(const rt_render_params* p) {
   return RT_OK;
 }
 
+/* The split of plan_tiles goes by a static estimate (triangles that project into a tile).  A frame whose mesh tiles
+ * are all resident at once lasts as long as its slowest wave, so the first launch with a new plan measures instead:
+ * every wave of a mesh tile's workgroup reports its cycle count, tiles whose slowest wave runs longer than the
+ * launch could take if its work were spread evenly (and longer than half the slowest of all) are split into twice
+ * as many parts (down to 4 x 1 pixels per wave), and the list is re-ordered longest first by what was measured.
+ * Up to split_refine rounds.  Every candidate list is a real render into the caller's image, timed with events; the
+ * list with the shortest launch is the one the plan keeps (a later one has to win by 2 %: mirror frames, whose
+ * lanes part ways after the first bounce, gain 25 % from finer parts, while a frame of primary and shadow rays
+ * alone walks nearly the same path in every lane of a tile and only pays for the extra workgroups). */
+int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s, RenderArgs& a, unsigned char* d_rgb,
+                 double* d_canvas, int& n_blocks) {
+  const int slots = cur->n_cu * 4 * (reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN);
+  const int rounds = plan->refine_left;
+  plan->refine_left = 0;
+  const int n_light = plan->entries - plan->heavy;
+  std::vector<int32_t> list = plan->host_list, best_list = list;
+  plan->host_list.clear();
+  plan->host_list.shrink_to_fit();
+  if (list.empty()) return RT_OK;
+  long long key[6];
+  memcpy(key, plan->key, sizeof key);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return RT_ERR_HIP; }
+  float best_ms = 1e30f;
+  bool current_is_best = true;
+  int rc = RT_OK;
+  auto adopt = [&](const std::vector<int32_t>& l) {
+    const int src = store_plan(plan, key, l, s);
+    if (src != RT_OK) return src;
+    plan->heavy = (int)l.size() - n_light;
+    plan->entries = (int)l.size();
+    cur->launch_tile_list = plan->d_list;
+    a.n_heavy = plan->heavy;
+    a.n_entries = plan->entries;
+    n_blocks = plan->heavy + (plan->entries - plan->heavy + cur->light_per_block - 1) / cur->light_per_block;
+    return (int)RT_OK;
+  };
+  for (int round = 0; round <= rounds && rc == RT_OK; ++round) {
+    const int nh = (int)list.size() - n_light;
+    unsigned* d_probe = nullptr;
+    if (!hip_ok(hipMalloc((void**)&d_probe, sizeof(unsigned) * 4 * (size_t)nh), "hipMalloc (split probe)")) { rc = RT_ERR_HIP; break; }
+    std::vector<unsigned> cyc((size_t)nh * 4, 0u);
+    float ms = 1e30f;
+    hipError_t e = hipMemsetAsync(d_probe, 0, sizeof(unsigned) * 4 * (size_t)nh, s);
+    for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) { /* the first run warms up, the shortest of the others counts */
+      a.probe = 1;
+      cur->launch_counters = reinterpret_cast<unsigned long long*>(d_probe);
+      e = hipEventRecord(e0, s);
+      launch(false, bvh, reflect, dim3((unsigned)n_blocks), s, a, d_rgb, d_canvas);
+      cur->launch_counters = nullptr;
+      a.probe = 0;
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e == hipSuccess) e = hipEventRecord(e1, s);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float one = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&one, e0, e1);
+      if (rep > 0 && one < ms) ms = one;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cyc.data(), d_probe, sizeof(unsigned) * cyc.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_probe);
+    if (!hip_ok(e, "split refinement probe")) { rc = RT_ERR_HIP; break; }
+    if (ms < best_ms * (round == 0 ? 1.0f : 0.98f)) {
+      best_ms = ms;
+      best_list = list;
+      current_is_best = true;
+    } else {
+      current_is_best = false;
+    }
+    std::vector<unsigned> cost((size_t)nh);
+    unsigned long long total = 0;
+    unsigned slowest = 0;
+    for (int i = 0; i < nh; ++i) {
+      unsigned m = 0;
+      for (int w = 0; w < 4; ++w) { m = std::max(m, cyc[(size_t)i * 4 + w]); total += cyc[(size_t)i * 4 + w]; }
+      cost[i] = m;
+      slowest = std::max(slowest, m);
+    }
+    const double even = (double)total / slots; /* cycles of a launch whose waves fill every slot to the end */
+    if (getenv("RT_HIP_VERBOSE")) {
+      int by_lg[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < nh; ++i) by_lg[std::min(4, (list[i] >> 28) & 7)]++;
+      fprintf(stderr, "refine_split round %d: %.1f us, %d mesh entries (parts 1/2/4/8/16: %d %d %d %d %d), slowest wave %u cycles, even %.0f\n",
+              round, ms * 1e3, nh, by_lg[0], by_lg[1], by_lg[2], by_lg[3], by_lg[4], slowest, even);
+    }
+    if (round == rounds || (double)slowest <= 1.15 * even) break;
+    const double threshold = std::max(even, 0.5 * (double)slowest);
+    struct Item { int32_t entry; double cost; };
+    std::vector<Item> items;
+    items.reserve((size_t)nh * 2);
+    bool any = false;
+    for (int i = 0; i < nh; ++i) {
+      const int32_t entry = list[i];
+      const int lg = (entry >> 28) & 7, part = (entry >> 24) & 15;
+      if ((double)cost[i] > threshold && lg < 4) {
+        const int32_t tile = entry & RT_TILE_MASK;
+        for (int h = 0; h < 2; ++h) items.push_back({tile | ((2 * part + h) << 24) | ((lg + 1) << 28), 0.6 * cost[i]});
+        any = true;
+      } else {
+        items.push_back({entry, (double)cost[i]});
+      }
+    }
+    if (!any) break;
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+    std::vector<int32_t> next;
+    next.reserve(items.size() + (size_t)n_light);
+    for (const Item& it : items) next.push_back(it.entry);
+    next.insert(next.end(), list.begin() + nh, list.end());
+    list.swap(next);
+    rc = adopt(list);
+    current_is_best = false;
+  }
+  if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
 /* Enqueue one render of the current context's scene on `s` and return at once.  timed: record the context's
  * event pair around the kernel; count: the counting build, counters zeroed first. */
 int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, bool timed, bool count,
@@ -806,6 +940,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
   const int W = cur->scene.hsize, H = cur->scene.vsize;
   const int rows = rt_hip_rank_rows(H, p->band_rows, p->n_ranks, p->rank);
   RenderArgs a;
+  a.probe = 0;
   a.max_depth = p->max_depth;
   a.spp_grid = p->spp_grid;
   a.band_rows = p->n_ranks > 1 ? p->band_rows : 1;
@@ -838,6 +973,10 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
     } else {
       const int prc = plan_tiles(p, rows, bvh, reflect, overlap, s, a, n_blocks);
       if (prc != RT_OK) return prc;
+      if (bvh && !count && cur->launch_plan && cur->launch_plan->refine_left > 0) {
+        const int rrc = refine_split(cur->launch_plan, bvh, reflect, s, a, d_rgb, d_canvas, n_blocks);
+        if (rrc != RT_OK) return rrc;
+      }
     }
     dim3 grid((unsigned)n_blocks);
     if (timed) HIP_TRY(hipEventRecord(cur->ev0, s));
@@ -1110,6 +1249,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_QUARTERS_REFLECT")) cur->split_quarters_reflect = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) cur->split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) cur->split_min_cost = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_REFINE")) cur->split_refine = atoi(e);
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */
