@@ -219,6 +219,19 @@ typedef struct rt_stats {
   uint64_t sphere_exact;    /* of sphere_tests                                    */
   double exchange_ms;       /* rt_hip_render_multi: hipEvent time on device 0 from the end of its own kernel
                                until every device's rows are in place (RCCL receive + placement); else 0 */
+  /* The sphere/triangle kernels keep a running (t, list position) minimum where the reference fills a list of
+   * 100 entries.  Two properties of that list have no counterpart in a minimum, and a world that triggers them
+   * renders differently from the reference unless it is rendered with RT_ACCEL_REFERENCE, whose kernel keeps
+   * the list itself.  With count_rays set these say whether the frame met them (both 0: it did not):
+   * zero_t_entries: intersections whose t is exactly 0.0 (a ray that starts exactly on a surface); such an
+   *   entry reads as a free slot to add_intersection and the next append overwrites it, RayTracer.c:168.
+   * list_cap_rays: rays that appended more than 100 entries (two per sphere with real roots, one per triangle
+   *   hit, of either sign of t); the reference drops the appends beyond INTERSECTIONS_SIZE, RayTracer.c:161.
+   *   Exact for camera and reflected rays under RT_ACCEL_BRUTE; a BVH walk and a shadow ray that stops at its
+   *   first blocker see fewer entries than the reference appends, so there the count is a lower bound.  A
+   *   world with 2 * spheres + triangles <= 100 cannot reach the cap at all. */
+  uint64_t zero_t_entries;
+  uint64_t list_cap_rays;
 } rt_stats;
 
 /* Create the context of HIP device `device` (stream, events) if it does not

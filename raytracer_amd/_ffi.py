@@ -143,6 +143,8 @@ class Stats(C.Structure):
         ("tri_exact", C.c_uint64),
         ("sphere_exact", C.c_uint64),
         ("exchange_ms", C.c_double),
+        ("zero_t_entries", C.c_uint64),
+        ("list_cap_rays", C.c_uint64),
     ]
 
     @property

@@ -957,7 +957,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
   const bool reflect = cur->reflective && p->max_depth >= 1;
   const bool overlap = (p->flags & RT_RENDER_FRAMES_OVERLAP) != 0;
   if (rows > 0) {
-    if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 8 * sizeof(unsigned long long), s));
+    if (count) HIP_TRY(hipMemsetAsync(cur->d_counters, 0, 10 * sizeof(unsigned long long), s));
     const long long n_tiles = (long long)((W + RT_TILE_W - 1) / RT_TILE_W) * ((rows + RT_TILE_H - 1) / RT_TILE_H);
     int n_blocks = 0;
     if (general) {
@@ -1005,7 +1005,7 @@ int render_collect(const Enqueued& e, hipStream_t s, rt_stats* stats) {
     stats->kernel_ms = ms;
   }
   if (e.count) {
-    unsigned long long c[8];
+    unsigned long long c[10];
     HIP_TRY(hipMemcpyAsync(c, cur->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     stats->rays_primary = c[0];
@@ -1016,6 +1016,8 @@ int render_collect(const Enqueued& e, hipStream_t s, rt_stats* stats) {
     stats->sphere_tests = c[5];
     stats->tri_exact = c[6];
     stats->sphere_exact = c[7];
+    stats->zero_t_entries = c[8];
+    stats->list_cap_rays = c[9];
   }
   return RT_OK;
 }
@@ -2135,6 +2137,7 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
       sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
       sum.prim_tests += one.prim_tests; sum.node_tests += one.node_tests; sum.sphere_tests += one.sphere_tests;
       sum.tri_exact += one.tri_exact; sum.sphere_exact += one.sphere_exact;
+      sum.zero_t_entries += one.zero_t_entries; sum.list_cap_rays += one.list_cap_rays;
       if (one.kernel_ms > sum.kernel_ms) sum.kernel_ms = one.kernel_ms; /* the devices run side by side */
       sum.rows_rendered += one.rows_rendered;
       sum.accel_used = one.accel_used;

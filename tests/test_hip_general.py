@@ -198,3 +198,45 @@ def test_fast_kernels_equal_the_list_kernel_on_the_gpu(hip, scene, w, h, tr, sr)
         assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (rst.rays_primary, rst.rays_shadow, rst.rays_secondary)
         assert_image_parity(got, ref, f"{scene} accel {accel}")
         assert np.array_equal(got, ref)
+
+
+def test_counting_build_reports_what_a_running_minimum_cannot_reproduce(hip):
+    """The sphere / triangle kernels keep a running minimum, not the reference's list.  Two worlds that make the list
+    behave unlike a minimum: the counting build reports both, the list kernel (RT_ACCEL_REFERENCE) renders them as the
+    reference does, and the ordinary scenes report zero."""
+    # an eye exactly in the plane of the first triangle: every camera ray gets an entry with t == 0.0, which the next
+    # append overwrites (RayTracer.c:168)
+    b = SceneBuilder()
+    b.set_camera(32, 24, 0.9, (0.0, 0.0, 0.0), (0.0, 0.0, -1.0))
+    b.set_light((-3.0, 4.0, 2.0), (1.0, 1.0, 1.0))
+    b.add_triangles_f32(np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0], [-4, -4, -3, 4, -4, -3, 0, 5, -3]], dtype=np.float32))
+    s = b.finish(1)
+    hip.upload(s)
+    want, _ = O.render_rgb(s)
+    for accel in (R._ffi.RT_ACCEL_BRUTE, R._ffi.RT_ACCEL_BVH):
+        fast, st = hip.render(accel=accel, count_rays=True)
+        assert st.zero_t_entries >= 32 * 24 and st.list_cap_rays == 0
+        assert not np.array_equal(fast, want)  # the divergence the counter is there to flag
+    ref, rst = hip.render(accel=R._ffi.RT_ACCEL_REFERENCE, count_rays=True)
+    assert np.array_equal(ref, want) and rst.zero_t_entries == 0  # the list kernel reproduces, so it has nothing to report
+
+    # 51 nested spheres: 102 entries on a ray through the middle, the reference keeps the first 100 (RayTracer.c:161)
+    b = SceneBuilder()
+    b.set_camera(40, 30, 0.5, (0.0, 0.0, -12.0), (0.0, 0.0, 0.0))
+    b.set_light((-5.0, 8.0, -10.0), (1.0, 1.0, 1.0))
+    for k in range(51):
+        b.add_sphere(Mat4.scale(*(3 * [0.5 + 0.05 * k])), default_material())
+    s = b.finish(0)
+    hip.upload(s)
+    want, _ = O.render_rgb(s)
+    assert O.probe().list_overflow > 0
+    _, st = hip.render(accel=R._ffi.RT_ACCEL_BRUTE, count_rays=True)
+    assert st.list_cap_rays > 0 and st.zero_t_entries == 0
+    ref, _ = hip.render(accel=R._ffi.RT_ACCEL_REFERENCE)
+    assert np.array_equal(ref, want)
+
+    for scene in ("cube", "spheres", "cube_spheres", "lighthouse"):
+        hip.upload(R.stock_scene(scene, 160, 120, 0.3, 0.3))
+        for accel in (R._ffi.RT_ACCEL_BRUTE, R._ffi.RT_ACCEL_BVH):
+            _, st = hip.render(accel=accel, count_rays=True)
+            assert st.zero_t_entries == 0 and st.list_cap_rays == 0
