@@ -46,6 +46,9 @@ struct Context {
   int device = -1;
   int n_cu = 256;
   int light_per_block = 20; /* background-only tiles per workgroup (filled five at a time) */
+  bool shadow_masks = true; /* ... and their shadow rays only the triangles that can lie between those and the light */
+  bool tile_masks = true;   /* meshes of up to 64 triangles: camera rays test only the triangles that cover their tile */
+  bool cover_tiles = true;  /* find the mesh tiles by rasterising the triangles (false: by the rectangle of the mesh's bounds) */
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
   bool lds_stack = true;
@@ -72,6 +75,10 @@ struct Context {
   double mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0}; /* world bounds of all triangles */
   double box_pad = 0.0; /* what every single-precision box is grown by */
   std::vector<float> tri_rect; /* pixel rectangle (x0 y0 x1 y1) of every triangle as the camera sees it; empty: unknown */
+  std::vector<double> tri_world; /* meshes of up to 64 triangles: the corners in world space (9 per triangle) */
+  double host_light[3] = {0, 0, 0};
+  std::vector<double> tri_xy;  /* where the camera sees the three corners of every triangle (x y x y x y, in pixels, pixel
+                                  k covering [k, k + 1)); empty: unknown, or a corner beside or behind the camera */
   /* tile orders of recent launches and the parameters each was made for (scene, bands, kernel family, overlap
    * mode): a caller that alternates between a few kinds of launch does not re-plan every time */
   struct TilePlan {
@@ -80,6 +87,9 @@ struct Context {
     size_t cap = 0;
     int heavy = 0, tiles = 0, entries = 0;
     bool light_background = false; /* the light tiles lie outside the mesh's pixel rectangle */
+    int light_per_block = 1;       /* light tiles per workgroup */
+    size_t mask_offset = 0;        /* d_list + mask_offset: two 64-bit triangle masks per entry (0: none): the triangles a
+                                      camera ray of the tile can hit, and those a shadow ray from such a hit can */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
     std::vector<int32_t> host_list; /* the list as uploaded, kept while refinements are pending */
     unsigned long long last_use = 0;
@@ -89,6 +99,7 @@ struct Context {
   unsigned long long plan_clock = 0;
   unsigned long long scene_serial = 0;
   const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
+  const unsigned long long* launch_tile_mask = nullptr; /* likewise: per-entry pairs of triangle masks, or nullptr */
   TilePlan* launch_plan = nullptr;           /* the plan it came from (plan_tiles), nullptr for an unplanned launch */
   unsigned long long* launch_counters = nullptr; /* counters argument of the launch being issued (nullptr: d_counters) */
   void* d_tri_primary = nullptr;
@@ -224,6 +235,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision forms: four workgroups still fit a CU */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
+constexpr int kMaxCoverTris = 1 << 16;     /* meshes up to this size are rasterised into the tile grid to find the tiles they cover */
 constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
 constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
@@ -234,7 +246,8 @@ void launch_one(size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsig
                      (const DevSphere*)cur->d_spheres, (const DevSpherePrimary*)cur->d_sph_primary, (const DevTri*)cur->d_tris,
                      (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const rt_material*)cur->d_materials,
                      (const DevBvh2*)cur->d_bvh, (const DevTriF*)cur->d_trif, (const DevSphereF*)cur->d_sphf, a,
-                     cur->launch_tile_list, rgb, canvas, cur->launch_counters ? cur->launch_counters : cur->d_counters);
+                     cur->launch_tile_list, cur->launch_tile_mask, rgb, canvas,
+                     cur->launch_counters ? cur->launch_counters : cur->d_counters);
 }
 /* kernels specialised for the primitive kinds the scene holds (KIND 1: spheres only, 2: triangles only, 0: both) */
 template <bool BVH, bool REFLECT, int STAGE>
@@ -373,6 +386,187 @@ int store_plan(Context::TilePlan* t, const long long key[6], const std::vector<i
   return RT_OK;
 }
 
+/* Which tiles of the launch can a camera ray reach a triangle through?  Every triangle's projection (a triangle
+ * again: all corners lie in front of the camera) is rasterised conservatively into the tile grid: a tile counts
+ * as covered unless it lies outside the triangle's pixel rectangle or wholly on the outer side of one of its
+ * edges, both with a margin of two pixels.  (The reference accepts a hit by u >= 0, v >= 0, u + v <= 1 in double
+ * precision; its rounding moves an edge by parts in 1e11 of the triangle's size, the projection here is rounded
+ * as finely, and a ray through a sub-pixel sample stays inside its pixel.)  A tile that is not covered shows
+ * nothing of a world without spheres, and in a covered tile the camera rays need to be tested against the
+ * triangles that cover it only (`masks`).  y_lo / y_hi: the image rows of every tile row (bands make them differ
+ * from the packed rows).  false: unknown. */
+bool covered_tiles(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const std::vector<int>& y_hi, bool rows_are_y,
+                   std::vector<unsigned char>& cover, std::vector<unsigned long long>* masks) {
+  if (cur->tri_xy.empty()) return false;
+  const double margin = 2.0;
+  cover.assign((size_t)tiles_x * tiles_y, 0);
+  const size_t nt = cur->tri_xy.size() / 6;
+  if (masks) masks->assign((size_t)tiles_x * tiles_y, 0ull); /* bit k of a tile: triangle k may be seen through it (nt <= 64) */
+  for (size_t k = 0; k < nt; ++k) {
+    const double* q = &cur->tri_xy[6 * k];
+    double bx0 = std::fmin(q[0], std::fmin(q[2], q[4])) - margin, bx1 = std::fmax(q[0], std::fmax(q[2], q[4])) + margin;
+    double by0 = std::fmin(q[1], std::fmin(q[3], q[5])) - margin, by1 = std::fmax(q[1], std::fmax(q[3], q[5])) + margin;
+    if (!(bx0 <= bx1 && by0 <= by1)) return false; /* NaN */
+    if (bx1 < 0.0 || by1 < 0.0 || bx0 > (double)tiles_x * RT_TILE_W) continue;
+    const int tx0 = std::max(0, (int)std::floor(bx0 / RT_TILE_W)), tx1 = std::min(tiles_x - 1, (int)std::floor(bx1 / RT_TILE_W));
+    /* edge functions, oriented so that the inside is >= 0; a sliver's orientation is not trusted (rectangle only) */
+    const double area2 = (q[2] - q[0]) * (q[5] - q[1]) - (q[3] - q[1]) * (q[4] - q[0]);
+    const double extent = (bx1 - bx0) + (by1 - by0);
+    const bool edges = std::fabs(area2) > 1e-6 * extent * extent;
+    const double sg = area2 > 0 ? 1.0 : -1.0;
+    int ty0 = 0, ty1 = tiles_y - 1;
+    if (rows_are_y) {
+      ty0 = std::max(0, (int)std::floor(by0 / RT_TILE_H));
+      ty1 = std::min(tiles_y - 1, (int)std::floor(by1 / RT_TILE_H));
+    }
+    for (int ty = ty0; ty <= ty1; ++ty) {
+      if ((double)y_hi[ty] + 1.0 < by0 || (double)y_lo[ty] > by1) continue;
+      const double ylo = (double)y_lo[ty] - margin, yhi = (double)y_hi[ty] + 1.0 + margin;
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        unsigned char& c = cover[(size_t)ty * tiles_x + tx];
+        if (c && !masks) continue;
+        bool out = false;
+        if (edges) {
+          const double xlo = (double)tx * RT_TILE_W - margin, xhi = (double)(tx + 1) * RT_TILE_W + margin;
+          for (int e = 0; e < 3 && !out; ++e) {
+            const double ax = q[2 * e], ay = q[2 * e + 1];
+            const double dx = sg * (q[2 * ((e + 1) % 3)] - ax), dy = sg * (q[2 * ((e + 1) % 3) + 1] - ay);
+            /* the corner of the (padded) tile that lies deepest on the inner side of the edge */
+            const double cx = dy < 0 ? xhi : xlo, cy = dx > 0 ? yhi : ylo;
+            out = dx * (cy - ay) - dy * (cx - ax) < 0.0;
+          }
+        }
+        if (!out) {
+          c = 1;
+          if (masks) (*masks)[(size_t)ty * tiles_x + tx] |= 1ull << k;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+
+struct V3 {
+  double x, y, z;
+};
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, double f) { return {a.x * f, a.y * f, a.z * f}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len(V3 a) { return std::sqrt(dot(a, a)); }
+
+/* Which triangles can stand between the light and a point that a camera ray through the pixel rectangle
+ * [x0, x1] x [y0, y1] sees on one of the triangles `seen`?  (A mesh of at most 64 triangles, no spheres, every
+ * corner in front of the camera.)  The points such a ray can see on triangle j are the part S of j inside the
+ * rectangle's four-sided pyramid of rays; is_shadowed (RayTracer.c:1410) sends its ray from a point EPSILON off
+ * the surface (:1371) to the light L and accepts hits on that stretch only, so everything it can meet lies within
+ * `pad` (several EPSILON, plus rounding at the scale of the scene) of the convex hull of S and L.  Triangle k is
+ * left out when a plane shows it to lie wholly outside that padded hull: the plane of j, a plane through L and
+ * an edge of S (the hull is a pyramid over S with its apex in L), or the plane of k itself.  Anything doubtful
+ * (a sliver, L almost in the plane of j) only loses planes to test with, never adds one. */
+unsigned long long shadow_blockers(double x0, double y0, double x1, double y1, unsigned long long seen, double pad) {
+  const rt_camera& cam = cur->host_camera;
+  const double* iv = cam.inv_view;
+  const size_t nt = cur->tri_world.size() / 9;
+  auto vert = [&](size_t k, int v) { const double* q = &cur->tri_world[9 * k + 3 * v]; return V3{q[0], q[1], q[2]}; };
+  const V3 O = {iv[3], iv[7], iv[11]}, L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
+  V3 d[4], dc = {0, 0, 0};
+  const double cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
+  for (int c = 0; c < 4; ++c) {
+    const double wx = cam.half_width - cx[c] * cam.pixel_size, wy = cam.half_height - cy[c] * cam.pixel_size;
+    d[c] = {iv[0] * wx + iv[1] * wy - iv[2], iv[4] * wx + iv[5] * wy - iv[6], iv[8] * wx + iv[9] * wy - iv[10]};
+    dc = dc + d[c];
+  }
+  V3 side[4];
+  for (int c = 0; c < 4; ++c) {
+    side[c] = cross(d[c], d[(c + 1) % 4]);
+    if (dot(side[c], dc) < 0) side[c] = side[c] * -1.0;
+  }
+  unsigned long long out = 0ull;
+  for (size_t j = 0; j < nt; ++j) {
+    if (!((seen >> j) & 1ull)) continue;
+    out |= 1ull << j;
+    /* S: triangle j clipped by the four side planes of the pyramid */
+    V3 poly[16], tmp[16];
+    int np = 3;
+    for (int v = 0; v < 3; ++v) poly[v] = vert(j, v);
+    for (int c = 0; c < 4 && np > 0; ++c) {
+      int nq = 0;
+      for (int i = 0; i < np; ++i) {
+        const V3 a = poly[i], b = poly[(i + 1) % np];
+        const double da = dot(side[c], a - O), db = dot(side[c], b - O);
+        if (da >= 0) tmp[nq++] = a;
+        if ((da >= 0) != (db >= 0)) tmp[nq++] = a + (b - a) * (da / (da - db));
+      }
+      np = nq;
+      for (int i = 0; i < np; ++i) poly[i] = tmp[i];
+    }
+    if (np < 1) continue; /* no camera ray of this tile reaches j after all */
+    /* planes that bound the hull of S and L: unit normal n, offset o, the hull within n . x - o >= 0 */
+    struct Plane { V3 n; double o, lo, hi; };
+    Plane pl[20];
+    int n_pl = 0;
+    const V3 p1 = vert(j, 0);
+    V3 nj = cross(vert(j, 1) - p1, vert(j, 2) - p1);
+    const double lj = len(nj);
+    if (lj > 0) {
+      nj = nj * (1.0 / lj);
+      const double dl = dot(nj, L - p1);
+      pl[n_pl++] = {nj, dot(nj, p1), std::fmin(0.0, dl), std::fmax(0.0, dl)};
+    }
+    for (int i = 0; i < np && np >= 3; ++i) {
+      const V3 a = poly[i] - L, b = poly[(i + 1) % np] - L;
+      V3 n = cross(a, b);
+      const double ln = len(n);
+      if (!(ln > 1e-12 * len(a) * len(b))) continue;
+      n = n * (1.0 / ln);
+      /* which side the rest of S lies on; an edge whose plane the other corners barely leave decides nothing */
+      double smin = 0.0, smax = 0.0;
+      for (int v = 0; v < np; ++v) {
+        const double sv = dot(n, poly[v] - L);
+        smin = std::fmin(smin, sv);
+        smax = std::fmax(smax, sv);
+      }
+      if (smax > pad && smin >= -1e-9 * (1.0 + smax)) pl[n_pl++] = {n, dot(n, L), 0.0, 1e300};
+      else if (smin < -pad && smax <= 1e-9 * (1.0 - smin)) pl[n_pl++] = {n * -1.0, -dot(n, L), 0.0, 1e300};
+    }
+    for (size_t k = 0; k < nt; ++k) {
+      if ((out >> k) & 1ull) continue;
+      const V3 kv[3] = {vert(k, 0), vert(k, 1), vert(k, 2)};
+      bool apart = false;
+      for (int q = 0; q < n_pl && !apart; ++q) {
+        const double s0 = dot(pl[q].n, kv[0]) - pl[q].o, s1 = dot(pl[q].n, kv[1]) - pl[q].o, s2 = dot(pl[q].n, kv[2]) - pl[q].o;
+        apart = (s0 < pl[q].lo - pad && s1 < pl[q].lo - pad && s2 < pl[q].lo - pad) ||
+                (s0 > pl[q].hi + pad && s1 > pl[q].hi + pad && s2 > pl[q].hi + pad);
+      }
+      if (!apart) {
+        /* the plane of k: S and L all on one side of it */
+        V3 nk = cross(kv[1] - kv[0], kv[2] - kv[0]);
+        const double lk = len(nk);
+        if (lk > 0) {
+          nk = nk * (1.0 / lk);
+          double lo = dot(nk, L - kv[0]), hi = lo;
+          for (int v = 0; v < np; ++v) {
+            const double sv = dot(nk, poly[v] - kv[0]);
+            lo = std::fmin(lo, sv);
+            hi = std::fmax(hi, sv);
+          }
+          apart = lo > pad || hi < -pad;
+        }
+      }
+      if (!apart) out |= 1ull << k;
+    }
+  }
+  return out;
+}
+
+/* Workgroups of a launch with `plan`: one per mesh entry, then the light tiles, light_per_block to a workgroup. */
+int plan_blocks(const Context::TilePlan* plan) {
+  return plan->heavy + (plan->entries - plan->heavy + plan->light_per_block - 1) / plan->light_per_block;
+}
+
 /* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
  * per workgroup).  Kept until the scene or the band layout changes. */
 int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool overlap, hipStream_t s, RenderArgs& a, int& n_blocks) {
@@ -380,6 +574,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const int n_tiles = tiles_x * tiles_y;
   cur->launch_tile_list = nullptr;
+  cur->launch_tile_mask = nullptr;
   cur->launch_plan = nullptr;
   a.n_heavy = n_tiles;
   a.light_per_block = 1;
@@ -400,17 +595,25 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   Context::TilePlan* const plan = find_plan(key, fresh);
   if (fresh) {
     std::vector<int32_t> heavy, light;
-    for (int ty = 0; ty < tiles_y; ++ty) {
-      /* image rows covered by this tile row (bands make packed rows non-contiguous in y) */
-      int ymin = 1 << 30, ymax = -1;
+    /* image rows covered by every tile row (bands make packed rows non-contiguous in y) */
+    std::vector<int> y_lo((size_t)tiles_y, 1 << 30), y_hi((size_t)tiles_y, -1);
+    for (int ty = 0; ty < tiles_y; ++ty)
       for (int r = ty * RT_TILE_H; r < (ty + 1) * RT_TILE_H && r < rows; ++r) {
         const int y = rt_hip_rank_row_to_y(r, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank);
-        ymin = y < ymin ? y : ymin;
-        ymax = y > ymax ? y : ymax;
+        y_lo[ty] = std::min(y_lo[ty], y);
+        y_hi[ty] = std::max(y_hi[ty], y);
       }
-      const bool row_hit = !have_rect || (ymax >= y0 && ymin <= y1);
+    /* the tiles the triangles cover, or (unknown) the tiles of the pixel rectangle of the mesh's bounds */
+    std::vector<unsigned char> cover;
+    std::vector<unsigned long long> masks;
+    const bool want_masks = !bvh && cur->tile_masks && cur->scene.n_tris <= 64;
+    const bool have_cover = have_rect && cur->cover_tiles &&
+                            covered_tiles(tiles_x, tiles_y, y_lo, y_hi, p->n_ranks <= 1, cover, want_masks ? &masks : nullptr);
+    for (int ty = 0; ty < tiles_y; ++ty) {
+      const bool row_hit = !have_rect || (y_hi[ty] >= y0 && y_lo[ty] <= y1);
       for (int tx = 0; tx < tiles_x; ++tx) {
-        const bool hit = row_hit && (!have_rect || ((tx + 1) * RT_TILE_W - 1 >= x0 && tx * RT_TILE_W <= x1));
+        bool hit = row_hit && (!have_rect || ((tx + 1) * RT_TILE_W - 1 >= x0 && tx * RT_TILE_W <= x1));
+        if (have_cover) hit = hit && cover[(size_t)ty * tiles_x + tx] != 0;
         (hit ? heavy : light).push_back(ty * tiles_x + tx);
       }
     }
@@ -516,6 +719,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     plan->heavy = (int)heavy.size();
     plan->tiles = n_tiles;
     plan->light_background = have_rect && !light.empty();
+    plan->light_per_block = cur->light_per_block;
     /* the split above goes by how many triangles project into a tile; the first launches with this plan measure
      * how long every wave really runs and split the slowest further (refine_split) */
     const bool was_split = bvh && cur->split_parts > 1 && cur->split_tiles > 0 && !cost.empty() &&
@@ -524,6 +728,29 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     plan->refine_left = was_split ? cur->split_refine : 0;
     heavy.insert(heavy.end(), light.begin(), light.end());
     plan->entries = (int)heavy.size();
+    plan->mask_offset = 0;
+    if (have_cover && want_masks) {
+      /* behind the entries (8-byte aligned): for every entry the triangles its camera rays have to be tested against */
+      if (heavy.size() % 2) heavy.push_back(0);
+      plan->mask_offset = heavy.size();
+      double reach = 1.0;
+      for (double v : cur->tri_world) reach = std::fmax(reach, std::fabs(v));
+      for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
+      const double pad = 8.0 * RT_EPSILON + 1e-9 * reach;
+      for (int e = 0; e < plan->entries; ++e) {
+        const int tile = heavy[e] & RT_TILE_MASK, tx = tile % tiles_x, ty = tile / tiles_x;
+        const unsigned long long m = masks[(size_t)tile];
+        /* the same two pixels of margin as the rasterisation that made m */
+        const unsigned long long all = cur->scene.n_tris >= 64 ? ~0ull : (1ull << cur->scene.n_tris) - 1ull;
+        const unsigned long long sh = m == 0ull || !cur->shadow_masks || cur->tri_world.empty() ? all
+                                      : shadow_blockers(tx * (double)RT_TILE_W - 2.0, (double)y_lo[ty] - 2.0, (tx + 1) * (double)RT_TILE_W + 2.0,
+                                                        (double)y_hi[ty] + 3.0, m, pad);
+        heavy.push_back((int32_t)(m & 0xffffffffull));
+        heavy.push_back((int32_t)(m >> 32));
+        heavy.push_back((int32_t)(sh & 0xffffffffull));
+        heavy.push_back((int32_t)(sh >> 32));
+      }
+    }
     const int src = store_plan(plan, key, heavy, s);
     if (src != RT_OK) return src;
     if (plan->refine_left > 0) plan->host_list = heavy;
@@ -531,11 +758,12 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   }
   cur->launch_plan = plan;
   cur->launch_tile_list = plan->d_list;
+  cur->launch_tile_mask = plan->mask_offset ? reinterpret_cast<const unsigned long long*>(plan->d_list + plan->mask_offset) : nullptr;
   a.n_heavy = plan->heavy;
-  a.light_per_block = cur->light_per_block;
+  a.light_per_block = plan->light_per_block;
   a.n_entries = plan->entries;
   a.light_is_background = plan->light_background ? 1 : 0;
-  n_blocks = plan->heavy + (plan->entries - plan->heavy + cur->light_per_block - 1) / cur->light_per_block;
+  n_blocks = plan_blocks(plan);
   return RT_OK;
 }
 
@@ -849,7 +1077,7 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     cur->launch_tile_list = plan->d_list;
     a.n_heavy = plan->heavy;
     a.n_entries = plan->entries;
-    n_blocks = plan->heavy + (plan->entries - plan->heavy + cur->light_per_block - 1) / cur->light_per_block;
+    n_blocks = plan_blocks(plan);
     return (int)RT_OK;
   };
   for (int round = 0; round <= rounds && rc == RT_OK; ++round) {
@@ -963,7 +1191,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
     if (general) {
       a.n_heavy = (int)n_tiles;
       a.light_per_block = 1;
-      a.ablate = 0; /* the timing cuts are the fast kernels'; this kernel reads the field as "probe launch" */
+          a.ablate = 0; /* the timing cuts are the fast kernels'; this kernel reads the field as "probe launch" */
       a.n_entries = 0;
       a.light_is_background = 0;
       n_blocks = (int)n_tiles;
@@ -1065,6 +1293,7 @@ int warm_launch() {
   a.light_per_block = 1;
   a.n_entries = 0;
   cur->launch_tile_list = nullptr;
+  cur->launch_tile_mask = nullptr;
   if (cur->general) launch_general(false, dim3(1), cur->stream, a, cur->d_rgb, nullptr);
   else launch(false, bvh, cur->reflective, dim3(1), cur->stream, a, cur->d_rgb, nullptr);
   HIP_TRY(hipGetLastError());
@@ -1238,7 +1467,7 @@ int create_context(int device) {
   HIP_TRY(hipEventCreate(&cur->tm0));
   HIP_TRY(hipEventCreate(&cur->tm1));
   HIP_TRY(hipEventCreateWithFlags(&cur->ppm_ev, hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void**)&cur->d_counters, (16 + (RT_STAMPS ? 6 * (size_t)RT_STAMPS_MAX_WAVES : 0)) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&cur->d_counters, (16 + (RT_STAMPS ? RT_STAMP_WORDS * (size_t)RT_STAMPS_MAX_WAVES : 0)) * sizeof(unsigned long long)));
   HIP_TRY(hipGetSymbolAddress((void**)&cur->ppm_scratch_ptr, HIP_SYMBOL(ppm_scratch)));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -1259,6 +1488,9 @@ int create_context(int device) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) cur->light_per_block = v;
   }
+  if (const char* e = getenv("RT_HIP_COVER_TILES")) cur->cover_tiles = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_TILE_MASKS")) cur->tile_masks = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_SHADOW_MASKS")) cur->shadow_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */
   cur->device = device;
   cur->ready = true;
@@ -1538,9 +1770,12 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   for (int c = 0; c < 3; ++c) { cur->mesh_lo[c] = blo[c] - pad; cur->mesh_hi[c] = bhi[c] + pad; }
   /* where each triangle lands on the image: the tile order of a launch puts crowded tiles first */
   cur->tri_rect.clear();
+  cur->tri_xy.clear();
   double view[16];
   if (nt > 0 && nt <= kMaxTilePlanTris && invert4(sc->camera.inv_view, view)) {
     cur->tri_rect.resize(4 * (size_t)nt);
+    bool all_in_front = nt <= kMaxCoverTris;
+    if (all_in_front) cur->tri_xy.resize(6 * (size_t)nt);
     const double W = sc->camera.hsize, H = sc->camera.vsize;
     for (int k = 0; k < nt; ++k) {
       const DevTri& t = ht[k];
@@ -1550,16 +1785,29 @@ int rt_hip_upload_scene(const rt_scene* sc) {
         for (int c = 0; c < 3; ++c) w[c] = t.p1[c] + (v == 1 ? t.e1[c] : (v == 2 ? t.e2[c] : 0.0));
         double c3[3];
         for (int r = 0; r < 3; ++r) c3[r] = view[4 * r] * w[0] + view[4 * r + 1] * w[1] + view[4 * r + 2] * w[2] + view[4 * r + 3];
-        if (!(c3[2] < -1e-6)) { x0 = 0.f; y0 = 0.f; x1 = (float)W; y1 = (float)H; break; } /* beside or behind the camera */
+        if (!(c3[2] < -1e-6)) { x0 = 0.f; y0 = 0.f; x1 = (float)W; y1 = (float)H; all_in_front = false; break; } /* beside or behind the camera */
         const double px = (sc->camera.half_width - c3[0] / -c3[2]) / sc->camera.pixel_size;
         const double py = (sc->camera.half_height - c3[1] / -c3[2]) / sc->camera.pixel_size;
+        if (all_in_front) { cur->tri_xy[6 * (size_t)k + 2 * v] = px; cur->tri_xy[6 * (size_t)k + 2 * v + 1] = py; }
         x0 = std::fmin(x0, (float)px); x1 = std::fmax(x1, (float)px);
         y0 = std::fmin(y0, (float)py); y1 = std::fmax(y1, (float)py);
       }
       float* q = &cur->tri_rect[4 * (size_t)k];
       q[0] = x0 - 1.f; q[1] = y0 - 1.f; q[2] = x1 + 1.f; q[3] = y1 + 1.f;
     }
+    if (!all_in_front) cur->tri_xy.clear();
   }
+  cur->tri_world.clear();
+  if (nt > 0 && nt <= 64) {
+    cur->tri_world.resize(9 * (size_t)nt);
+    for (int k = 0; k < nt; ++k)
+      for (int c = 0; c < 3; ++c) {
+        cur->tri_world[9 * (size_t)k + c] = ht[k].p1[c];
+        cur->tri_world[9 * (size_t)k + 3 + c] = ht[k].p1[c] + ht[k].e1[c];
+        cur->tri_world[9 * (size_t)k + 6 + c] = ht[k].p1[c] + ht[k].e2[c];
+      }
+  }
+  for (int c = 0; c < 3; ++c) cur->host_light[c] = sc->light.position[c];
   cur->box_pad = pad;
   cur->scene_serial++;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);
@@ -2152,11 +2400,12 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
 }
 
 #if RT_STAMPS
-/* development builds: the per-wave time stamps of the last launch (6 words per wave) */
+/* development builds: the per-wave time stamps of the last launch (rt_hip_debug_stamp_words() words per wave) */
+int rt_hip_debug_stamp_words(void) { return RT_STAMP_WORDS; }
 int rt_hip_debug_stamps(unsigned long long* out, int n_waves) {
   if (!cur->ready || n_waves < 0 || n_waves > RT_STAMPS_MAX_WAVES) return RT_ERR_INVALID;
   HIP_TRY(hipStreamSynchronize(cur->stream));
-  HIP_TRY(hipMemcpy(out, cur->d_counters + 16, sizeof(unsigned long long) * 6 * (size_t)n_waves, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, cur->d_counters + 16, sizeof(unsigned long long) * RT_STAMP_WORDS * (size_t)n_waves, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 #endif

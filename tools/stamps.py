@@ -19,7 +19,8 @@ for _ in range(50):
     hip.render_device(buf.data_ptr(), p)
 torch.cuda.synchronize()
 NW = 65536
-raw = np.zeros((NW, 6), dtype=np.uint64)
+WORDS = L.rt_hip_debug_stamp_words()
+raw = np.zeros((NW, WORDS), dtype=np.uint64)
 L.rt_hip_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 assert L.rt_hip_debug_stamps(raw.ctypes.data, NW) == 0
 used = raw[:, 3] > 0
@@ -39,6 +40,12 @@ for name, m in (("heavy", heavy), ("light", ~heavy)):
         print(f"{name:5s} waves: duration median {np.median(d):.2f} us, 90% {np.percentile(d, 90):.2f}, max {d.max():.2f}; "
               f"start median {np.median(start_us[m]):.2f}, max {start_us[m].max():.2f}; end max {end_us[m].max():.2f}; "
               f"shader-clock/wall ratio {np.median(cyc[m] / np.maximum(dur_us[m], 0.01)):.0f} ticks/us")
+if WORDS > 6:  # -DRT_PHASES=1: shader-clock ticks per phase, summed over the heavy waves
+    ph = s[heavy][:, 6:14].astype(np.float64)
+    names = ["ray generation", "nearest hit", "hit point, shadow ray", "shadow ray", "lighting", "store", "start-up, staging", "-"]
+    tot = ph.sum()
+    print("phases of heavy waves (share of their ticks; median ticks per wave):",
+          [(names[k], round(float(ph[:, k].sum() / tot), 3), int(np.median(ph[:, k]))) for k in range(7)])
 print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
 hist, edges = np.histogram(end_us, bins=12)
 print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
