@@ -220,6 +220,22 @@ void make_spheref(const double* inv, const double* origin, double radius, DevSph
   for (int r = 0; r < 3; ++r)
     out->po[r] = (float)(((origin[0] * inv[4 * r] + origin[1] * inv[4 * r + 1]) + origin[2] * inv[4 * r + 2]) + inv[4 * r + 3]);
   out->k = (omax * mn < 1e15 && k < 1e30) ? (float)k : INFINITY; /* NaN compares false: infinite */
+  /* for the "outside and leading away" test of sphere_filter: norms rounded up, and the camera origin's own c,
+   * which the host knows in double precision (with the reference's expression, RayTracer.c:927) */
+  out->mn = std::nextafterf((float)mn, INFINITY);
+  out->tn = std::nextafterf((float)tn, INFINITY);
+  double o[3];
+  for (int r = 0; r < 3; ++r) o[r] = ((origin[0] * inv[4 * r] + origin[1] * inv[4 * r + 1]) + origin[2] * inv[4 * r + 2]) + inv[4 * r + 3];
+  const double ss = (o[0] * o[0] + o[1] * o[1]) + o[2] * o[2];
+  out->primary_outside = (ss - 1.0 > 2e-3 * ss && ss < 1e30) ? 1.0f : 0.0f;
+  /* A shadow ray that starts on this sphere starts at inv (p + EPSILON n) = o' + EPSILON inv n with n = the unit
+   * vector along inv^T o', i.e. c = 2 EPSILON |inv^T o'| + (rounding of the hit point, ~4e-16 Mn radius) with
+   * |inv^T o'| >= the least singular value of inv >= |det inv| / Mn^2.  The rule "such a ray that leads away from
+   * the centre meets nothing" is used only where the first term is a thousand times the second. */
+  const double det = inv[0] * (inv[5] * inv[10] - inv[6] * inv[9]) - inv[1] * (inv[4] * inv[10] - inv[6] * inv[8]) +
+                     inv[2] * (inv[4] * inv[9] - inv[5] * inv[8]);
+  const double sigma_min = mn > 0 ? std::fabs(det) / (mn * mn) : 0.0;
+  out->self_ok = (2.0 * RT_EPSILON * sigma_min > 1e3 * 4e-16 * mn * std::fmax(radius, 1.0) && sigma_min > 1e-6) ? 1.0f : 0.0f;
 }
 
 int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
