@@ -46,6 +46,7 @@ struct Context {
   int device = -1;
   int n_cu = 256;
   int light_per_block = 20; /* background-only tiles per workgroup (filled five at a time) */
+  bool sphere_masks = true; /* worlds with up to 64 spheres: masks for them as well */
   bool shadow_masks = true; /* ... and their shadow rays only the triangles that can lie between those and the light */
   bool tile_masks = true;   /* meshes of up to 64 triangles: camera rays test only the triangles that cover their tile */
   bool cover_tiles = true;  /* find the mesh tiles by rasterising the triangles (false: by the rectangle of the mesh's bounds) */
@@ -76,6 +77,10 @@ struct Context {
   double box_pad = 0.0; /* what every single-precision box is grown by */
   std::vector<float> tri_rect; /* pixel rectangle (x0 y0 x1 y1) of every triangle as the camera sees it; empty: unknown */
   std::vector<double> tri_world; /* meshes of up to 64 triangles: the corners in world space (9 per triangle) */
+  /* worlds of up to 64 spheres: rows 0..2 of every inverse transform, its Frobenius norm, and the eight corners of the
+   * box that holds the sphere (the image of [-1, 1]^3; corner v has +1 where bit 0 / 1 / 2 of v is set) in world space
+   * and as the camera sees them (pixels; NaN: a corner beside or behind the camera) */
+  std::vector<double> sph_inv, sph_norm, sph_world, sph_xy;
   double host_light[3] = {0, 0, 0};
   std::vector<double> tri_xy;  /* where the camera sees the three corners of every triangle (x y x y x y, in pixels, pixel
                                   k covering [k, k + 1)); empty: unknown, or a corner beside or behind the camera */
@@ -88,8 +93,8 @@ struct Context {
     int heavy = 0, tiles = 0, entries = 0;
     bool light_background = false; /* the light tiles lie outside the mesh's pixel rectangle */
     int light_per_block = 1;       /* light tiles per workgroup */
-    size_t mask_offset = 0;        /* d_list + mask_offset: two 64-bit triangle masks per entry (0: none): the triangles a
-                                      camera ray of the tile can hit, and those a shadow ray from such a hit can */
+    size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
+                                      ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
     std::vector<int32_t> host_list; /* the list as uploaded, kept while refinements are pending */
     unsigned long long last_use = 0;
@@ -473,20 +478,26 @@ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline double len(V3 a) { return std::sqrt(dot(a, a)); }
 
-/* Which triangles can stand between the light and a point that a camera ray through the pixel rectangle
- * [x0, x1] x [y0, y1] sees on one of the triangles `seen`?  (A mesh of at most 64 triangles, no spheres, every
- * corner in front of the camera.)  The points such a ray can see on triangle j are the part S of j inside the
- * rectangle's four-sided pyramid of rays; is_shadowed (RayTracer.c:1410) sends its ray from a point EPSILON off
- * the surface (:1371) to the light L and accepts hits on that stretch only, so everything it can meet lies within
- * `pad` (several EPSILON, plus rounding at the scale of the scene) of the convex hull of S and L.  Triangle k is
- * left out when a plane shows it to lie wholly outside that padded hull: the plane of j, a plane through L and
- * an edge of S (the hull is a pyramid over S with its apex in L), or the plane of k itself.  Anything doubtful
- * (a sliver, L almost in the plane of j) only loses planes to test with, never adds one. */
-unsigned long long shadow_blockers(double x0, double y0, double x1, double y1, unsigned long long seen, double pad) {
+/* Which primitives can stand between the light and a point that a camera ray through the pixel rectangle
+ * [x0, x1] x [y0, y1] sees on one of the triangles `seen_tri` or spheres `seen_sph`?  (A world of at most 64
+ * triangles and 64 spheres, every corner of every triangle and of every sphere's box in front of the camera; a
+ * sphere's box: the image of [-1, 1]^3 under its transform.)  The points such a ray can see on primitive j lie in
+ * S = the part of j (a sphere: of its box) inside the rectangle's four-sided pyramid of rays; is_shadowed
+ * (RayTracer.c:1410) sends its ray from a point EPSILON off the surface (:1371) to the light L and accepts hits on
+ * that stretch only, so everything it can meet lies within `pad` (several EPSILON, plus rounding at the scale of
+ * the scene) of the convex hull of S and L.  Primitive k is left out when a plane shows it to lie wholly outside
+ * that padded hull.  The planes tried: for a triangle j, its own plane and the planes through L and an edge of S
+ * (the hull is a pyramid over S with its apex in L); the plane of a triangle k; the six faces of the box of a
+ * sphere k.  Anything doubtful (a sliver, L almost in the plane of j, an eye inside a box) only loses planes to
+ * test with, or keeps everything. */
+void shadow_blockers(double x0, double y0, double x1, double y1, unsigned long long seen_tri, unsigned long long seen_sph, double pad,
+                     unsigned long long& block_tri, unsigned long long& block_sph) {
   const rt_camera& cam = cur->host_camera;
   const double* iv = cam.inv_view;
-  const size_t nt = cur->tri_world.size() / 9;
+  const size_t nt = cur->tri_world.size() / 9, ns = cur->sph_world.size() / 24;
+  const unsigned long long all_tri = nt >= 64 ? ~0ull : (1ull << nt) - 1ull, all_sph = ns >= 64 ? ~0ull : (1ull << ns) - 1ull;
   auto vert = [&](size_t k, int v) { const double* q = &cur->tri_world[9 * k + 3 * v]; return V3{q[0], q[1], q[2]}; };
+  auto corner = [&](size_t k, int v) { const double* q = &cur->sph_world[24 * k + 3 * v]; return V3{q[0], q[1], q[2]}; };
   const V3 O = {iv[3], iv[7], iv[11]}, L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
   V3 d[4], dc = {0, 0, 0};
   const double cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
@@ -500,14 +511,9 @@ unsigned long long shadow_blockers(double x0, double y0, double x1, double y1, u
     side[c] = cross(d[c], d[(c + 1) % 4]);
     if (dot(side[c], dc) < 0) side[c] = side[c] * -1.0;
   }
-  unsigned long long out = 0ull;
-  for (size_t j = 0; j < nt; ++j) {
-    if (!((seen >> j) & 1ull)) continue;
-    out |= 1ull << j;
-    /* S: triangle j clipped by the four side planes of the pyramid */
-    V3 poly[16], tmp[16];
-    int np = 3;
-    for (int v = 0; v < 3; ++v) poly[v] = vert(j, v);
+  /* a convex polygon clipped by the four side planes of the pyramid (in place; returns the number of corners) */
+  auto clip = [&](V3* poly, int np) {
+    V3 tmp[16];
     for (int c = 0; c < 4 && np > 0; ++c) {
       int nq = 0;
       for (int i = 0; i < np; ++i) {
@@ -519,9 +525,71 @@ unsigned long long shadow_blockers(double x0, double y0, double x1, double y1, u
       np = nq;
       for (int i = 0; i < np; ++i) poly[i] = tmp[i];
     }
+    return np;
+  };
+  struct Plane { V3 n; double o, lo, hi; }; /* the hull within lo <= n . x - o <= hi */
+  /* everything a hull of `pts` (np points) and L cannot be told apart from, given planes that bound that hull */
+  auto add_blockers = [&](const V3* pts, int np, const Plane* pl, int n_pl) {
+    auto apart_by_planes = [&](const V3* kv, int nk) {
+      for (int q = 0; q < n_pl; ++q) {
+        bool below = true, above = true;
+        for (int v = 0; v < nk; ++v) {
+          const double sv = dot(pl[q].n, kv[v]) - pl[q].o;
+          below = below && sv < pl[q].lo - pad;
+          above = above && sv > pl[q].hi + pad;
+        }
+        if (below || above) return true;
+      }
+      return false;
+    };
+    for (size_t k = 0; k < nt; ++k) {
+      if ((block_tri >> k) & 1ull) continue;
+      const V3 kv[3] = {vert(k, 0), vert(k, 1), vert(k, 2)};
+      bool apart = apart_by_planes(kv, 3);
+      if (!apart) { /* the plane of k: the points and L all on one side of it */
+        V3 nk = cross(kv[1] - kv[0], kv[2] - kv[0]);
+        const double lk = len(nk);
+        if (lk > 0) {
+          nk = nk * (1.0 / lk);
+          double lo = dot(nk, L - kv[0]), hi = lo;
+          for (int v = 0; v < np; ++v) {
+            const double sv = dot(nk, pts[v] - kv[0]);
+            lo = std::fmin(lo, sv);
+            hi = std::fmax(hi, sv);
+          }
+          apart = lo > pad || hi < -pad;
+        }
+      }
+      if (!apart) block_tri |= 1ull << k;
+    }
+    for (size_t k = 0; k < ns; ++k) {
+      if ((block_sph >> k) & 1ull) continue;
+      V3 kv[8];
+      for (int v = 0; v < 8; ++v) kv[v] = corner(k, v);
+      bool apart = apart_by_planes(kv, 8);
+      if (!apart) { /* the faces of k's box: the points and L all beyond one of them, in k's object space */
+        const double* m = &cur->sph_inv[12 * k];
+        const double padk = pad * cur->sph_norm[k];
+        for (int r = 0; r < 3 && !apart; ++r) {
+          double lo = m[4 * r] * L.x + m[4 * r + 1] * L.y + m[4 * r + 2] * L.z + m[4 * r + 3], hi = lo;
+          for (int v = 0; v < np; ++v) {
+            const double sv = m[4 * r] * pts[v].x + m[4 * r + 1] * pts[v].y + m[4 * r + 2] * pts[v].z + m[4 * r + 3];
+            lo = std::fmin(lo, sv);
+            hi = std::fmax(hi, sv);
+          }
+          apart = lo > 1.0 + padk || hi < -1.0 - padk;
+        }
+      }
+      if (!apart) block_sph |= 1ull << k;
+    }
+  };
+  for (size_t j = 0; j < nt; ++j) {
+    if (!((seen_tri >> j) & 1ull)) continue;
+    block_tri |= 1ull << j;
+    V3 poly[16];
+    for (int v = 0; v < 3; ++v) poly[v] = vert(j, v);
+    const int np = clip(poly, 3);
     if (np < 1) continue; /* no camera ray of this tile reaches j after all */
-    /* planes that bound the hull of S and L: unit normal n, offset o, the hull within n . x - o >= 0 */
-    struct Plane { V3 n; double o, lo, hi; };
     Plane pl[20];
     int n_pl = 0;
     const V3 p1 = vert(j, 0);
@@ -548,39 +616,130 @@ unsigned long long shadow_blockers(double x0, double y0, double x1, double y1, u
       if (smax > pad && smin >= -1e-9 * (1.0 + smax)) pl[n_pl++] = {n, dot(n, L), 0.0, 1e300};
       else if (smin < -pad && smax <= 1e-9 * (1.0 - smin)) pl[n_pl++] = {n * -1.0, -dot(n, L), 0.0, 1e300};
     }
-    for (size_t k = 0; k < nt; ++k) {
-      if ((out >> k) & 1ull) continue;
-      const V3 kv[3] = {vert(k, 0), vert(k, 1), vert(k, 2)};
-      bool apart = false;
-      for (int q = 0; q < n_pl && !apart; ++q) {
-        const double s0 = dot(pl[q].n, kv[0]) - pl[q].o, s1 = dot(pl[q].n, kv[1]) - pl[q].o, s2 = dot(pl[q].n, kv[2]) - pl[q].o;
-        apart = (s0 < pl[q].lo - pad && s1 < pl[q].lo - pad && s2 < pl[q].lo - pad) ||
-                (s0 > pl[q].hi + pad && s1 > pl[q].hi + pad && s2 > pl[q].hi + pad);
-      }
-      if (!apart) {
-        /* the plane of k: S and L all on one side of it */
-        V3 nk = cross(kv[1] - kv[0], kv[2] - kv[0]);
-        const double lk = len(nk);
-        if (lk > 0) {
-          nk = nk * (1.0 / lk);
-          double lo = dot(nk, L - kv[0]), hi = lo;
-          for (int v = 0; v < np; ++v) {
-            const double sv = dot(nk, poly[v] - kv[0]);
-            lo = std::fmin(lo, sv);
-            hi = std::fmax(hi, sv);
-          }
-          apart = lo > pad || hi < -pad;
-        }
-      }
-      if (!apart) out |= 1ull << k;
-    }
+    add_blockers(poly, np, pl, n_pl);
   }
-  return out;
+  for (size_t j = 0; j < ns; ++j) {
+    if (!((seen_sph >> j) & 1ull)) continue;
+    block_sph |= 1ull << j;
+    /* an eye inside the box sees its inside: no S worth the name */
+    const double* m = &cur->sph_inv[12 * j];
+    bool eye_inside = true;
+    for (int r = 0; r < 3; ++r)
+      eye_inside = eye_inside && std::fabs(m[4 * r] * O.x + m[4 * r + 1] * O.y + m[4 * r + 2] * O.z + m[4 * r + 3]) <= 1.0 + 1e-6;
+    if (eye_inside) { block_tri = all_tri; block_sph = all_sph; return; }
+    /* S: the corners of the six faces of the box, each face clipped by the pyramid */
+    V3 pts[6 * 16];
+    int np = 0;
+    for (int axis = 0; axis < 3; ++axis)
+      for (int side_ = 0; side_ < 2; ++side_) {
+        const int b1 = (axis + 1) % 3, b2 = (axis + 2) % 3;
+        V3 quad[16];
+        const int loop[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+        for (int v = 0; v < 4; ++v) quad[v] = corner(j, (side_ << axis) | (loop[v][0] << b1) | (loop[v][1] << b2));
+        const int nq = clip(quad, 4);
+        for (int v = 0; v < nq; ++v) pts[np++] = quad[v];
+      }
+    if (np < 1) continue;
+    add_blockers(pts, np, nullptr, 0);
+  }
 }
 
 /* Workgroups of a launch with `plan`: one per mesh entry, then the light tiles, light_per_block to a workgroup. */
 int plan_blocks(const Context::TilePlan* plan) {
   return plan->heavy + (plan->entries - plan->heavy + plan->light_per_block - 1) / plan->light_per_block;
+}
+
+/* The tile plan of a world with spheres (at most 64, and at most 64 triangles, no BVH in use): tiles in raster
+ * order, those that no triangle and no sphere's box reaches last (they show nothing), and four masks per entry:
+ * the triangles and the spheres a camera ray of the tile can hit, and the triangles and the spheres that can
+ * stand between such a hit and the light (shadow_blockers).  false: no such plan for this world. */
+bool masked_world(bool bvh) {
+  const int ns = cur->scene.n_spheres, nt = cur->scene.n_tris;
+  return cur->tile_plan && cur->tile_masks && cur->sphere_masks && !bvh && ns >= 1 && ns <= 64 && nt <= 64 && !cur->sph_world.empty() &&
+         !cur->sph_xy.empty() && (nt == 0 || (!cur->tri_xy.empty() && !cur->tri_world.empty()));
+}
+int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStream_t s, RenderArgs& a, int& n_blocks) {
+  const int W = cur->scene.hsize, ns = cur->scene.n_spheres, nt = cur->scene.n_tris;
+  const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+  const long long key[6] = {(long long)cur->scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
+                            (1ll << 20) + cur->light_per_block * 8 + (reflect ? 4 : 0)};
+  bool fresh = false;
+  Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh) {
+    std::vector<int> y_lo((size_t)tiles_y, 1 << 30), y_hi((size_t)tiles_y, -1);
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int r = ty * RT_TILE_H; r < (ty + 1) * RT_TILE_H && r < rows; ++r) {
+        const int y = rt_hip_rank_row_to_y(r, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank);
+        y_lo[ty] = std::min(y_lo[ty], y);
+        y_hi[ty] = std::max(y_hi[ty], y);
+      }
+    std::vector<unsigned char> cover;
+    std::vector<unsigned long long> tri_mask((size_t)tiles_x * tiles_y, 0ull), sph_mask((size_t)tiles_x * tiles_y, 0ull);
+    if (nt > 0 && !covered_tiles(tiles_x, tiles_y, y_lo, y_hi, p->n_ranks <= 1, cover, &tri_mask)) return RT_ERR_INVALID;
+    const double margin = 2.0;
+    for (int j = 0; j < ns; ++j) { /* the pixel rectangle of the box of sphere j */
+      const double* q = &cur->sph_xy[16 * (size_t)j];
+      double bx0 = 1e300, by0 = 1e300, bx1 = -1e300, by1 = -1e300;
+      bool whole = false;
+      for (int v = 0; v < 8; ++v) {
+        whole = whole || !(std::isfinite(q[2 * v]) && std::isfinite(q[2 * v + 1]));
+        bx0 = std::fmin(bx0, q[2 * v]); bx1 = std::fmax(bx1, q[2 * v]);
+        by0 = std::fmin(by0, q[2 * v + 1]); by1 = std::fmax(by1, q[2 * v + 1]);
+      }
+      if (whole) { /* a box that reaches beside or behind the camera: any pixel may see it */
+        bx0 = by0 = -1e300;
+        bx1 = by1 = 1e300;
+      }
+      bx0 -= margin; by0 -= margin; bx1 += margin; by1 += margin;
+      const int tx0 = (int)std::fmax(0.0, std::floor(bx0 / RT_TILE_W)), tx1 = (int)std::fmin((double)tiles_x - 1, std::floor(bx1 / RT_TILE_W));
+      for (int ty = 0; ty < tiles_y; ++ty) {
+        if ((double)y_hi[ty] + 1.0 < by0 || (double)y_lo[ty] > by1) continue;
+        for (int tx = tx0; tx <= tx1; ++tx) sph_mask[(size_t)ty * tiles_x + tx] |= 1ull << j;
+      }
+    }
+    std::vector<int32_t> list, light;
+    for (int t = 0; t < tiles_x * tiles_y; ++t) (tri_mask[t] | sph_mask[t] ? list : light).push_back(t);
+    plan->heavy = (int)list.size();
+    plan->tiles = tiles_x * tiles_y;
+    plan->light_background = !light.empty();
+    plan->light_per_block = cur->light_per_block;
+    plan->refine_left = 0;
+    plan->host_list.clear();
+    list.insert(list.end(), light.begin(), light.end());
+    plan->entries = (int)list.size();
+    if (list.size() % 2) list.push_back(0);
+    plan->mask_offset = list.size();
+    double reach = 1.0;
+    for (double v : cur->tri_world) reach = std::fmax(reach, std::fabs(v));
+    for (double v : cur->sph_world) reach = std::fmax(reach, std::fabs(v));
+    for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
+    const double pad = 8.0 * RT_EPSILON + 1e-9 * reach;
+    const unsigned long long all_tri = nt >= 64 ? ~0ull : (1ull << nt) - 1ull, all_sph = ns >= 64 ? ~0ull : (1ull << ns) - 1ull;
+    for (int e = 0; e < plan->entries; ++e) {
+      const int tile = list[e], tx = tile % tiles_x, ty = tile / tiles_x;
+      unsigned long long m[4] = {tri_mask[tile], all_tri, sph_mask[tile], all_sph};
+      if (cur->shadow_masks) {
+        m[1] = m[3] = 0ull;
+        shadow_blockers(tx * (double)RT_TILE_W - margin, (double)y_lo[ty] - margin, (tx + 1) * (double)RT_TILE_W + margin,
+                        (double)y_hi[ty] + 1.0 + margin, m[0], m[2], pad, m[1], m[3]);
+      }
+      for (int k = 0; k < 4; ++k) {
+        list.push_back((int32_t)(m[k] & 0xffffffffull));
+        list.push_back((int32_t)(m[k] >> 32));
+      }
+    }
+    const int src = store_plan(plan, key, list, s);
+    if (src != RT_OK) return src;
+  }
+  cur->launch_plan = plan;
+  cur->launch_tile_list = plan->d_list;
+  cur->launch_tile_mask = reinterpret_cast<const unsigned long long*>(plan->d_list + plan->mask_offset);
+  a.n_heavy = plan->heavy;
+  a.light_per_block = plan->light_per_block;
+  a.n_entries = plan->entries;
+  a.light_is_background = plan->light_background ? 1 : 0;
+  n_blocks = plan_blocks(plan);
+  return RT_OK;
 }
 
 /* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
@@ -598,6 +757,13 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.light_is_background = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
+  if (masked_world(bvh) && cur->light_per_block > 1) {
+    const int mrc = plan_masked_world(p, rows, reflect, s, a, n_blocks);
+    if (mrc != RT_ERR_INVALID) return mrc; /* RT_ERR_INVALID: not this way after all */
+    cur->launch_tile_list = nullptr;
+    cur->launch_tile_mask = nullptr;
+    cur->launch_plan = nullptr;
+  }
   /* with spheres in the world any pixel may be expensive; without triangles there is nothing to sort by */
   if (!cur->tile_plan || cur->scene.n_tris == 0 || cur->light_per_block <= 1) return RT_OK;
   const bool tree_in_memory = cur->scene.n_bvh_nodes > kMaxLdsBvhNodes;
@@ -758,13 +924,17 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
         const unsigned long long m = masks[(size_t)tile];
         /* the same two pixels of margin as the rasterisation that made m */
         const unsigned long long all = cur->scene.n_tris >= 64 ? ~0ull : (1ull << cur->scene.n_tris) - 1ull;
-        const unsigned long long sh = m == 0ull || !cur->shadow_masks || cur->tri_world.empty() ? all
-                                      : shadow_blockers(tx * (double)RT_TILE_W - 2.0, (double)y_lo[ty] - 2.0, (tx + 1) * (double)RT_TILE_W + 2.0,
-                                                        (double)y_hi[ty] + 3.0, m, pad);
+        unsigned long long sh = all, none = 0ull;
+        if (m != 0ull && cur->shadow_masks && !cur->tri_world.empty()) {
+          sh = 0ull;
+          shadow_blockers(tx * (double)RT_TILE_W - 2.0, (double)y_lo[ty] - 2.0, (tx + 1) * (double)RT_TILE_W + 2.0, (double)y_hi[ty] + 3.0, m,
+                          0ull, pad, sh, none);
+        }
         heavy.push_back((int32_t)(m & 0xffffffffull));
         heavy.push_back((int32_t)(m >> 32));
         heavy.push_back((int32_t)(sh & 0xffffffffull));
         heavy.push_back((int32_t)(sh >> 32));
+        for (int k = 0; k < 4; ++k) heavy.push_back(0); /* the two masks of the spheres: there are none */
       }
     }
     const int src = store_plan(plan, key, heavy, s);
@@ -1507,6 +1677,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_COVER_TILES")) cur->cover_tiles = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_MASKS")) cur->tile_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SHADOW_MASKS")) cur->shadow_masks = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_SPHERE_MASKS")) cur->sphere_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */
   cur->device = device;
   cur->ready = true;
@@ -1824,6 +1995,44 @@ int rt_hip_upload_scene(const rt_scene* sc) {
       }
   }
   for (int c = 0; c < 3; ++c) cur->host_light[c] = sc->light.position[c];
+  /* the boxes of the spheres, in the world and on the image */
+  cur->sph_inv.clear();
+  cur->sph_norm.clear();
+  cur->sph_world.clear();
+  cur->sph_xy.clear();
+  double view_s[16];
+  if (ns > 0 && ns <= 64 && invert4(sc->camera.inv_view, view_s)) {
+    bool ok = true;
+    cur->sph_inv.resize(12 * (size_t)ns);
+    cur->sph_norm.resize((size_t)ns);
+    cur->sph_world.resize(24 * (size_t)ns);
+    cur->sph_xy.resize(16 * (size_t)ns);
+    for (int i = 0; i < ns && ok; ++i) {
+      double inv4[16], fwd[16], n2 = 0.0;
+      memcpy(inv4, hs[i].inv, 12 * sizeof(double));
+      inv4[12] = inv4[13] = inv4[14] = 0.0;
+      inv4[15] = 1.0;
+      ok = invert4(inv4, fwd);
+      memcpy(&cur->sph_inv[12 * (size_t)i], hs[i].inv, 12 * sizeof(double));
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) n2 += inv4[4 * r + c] * inv4[4 * r + c];
+      cur->sph_norm[i] = std::sqrt(n2);
+      for (int v = 0; v < 8 && ok; ++v) {
+        const double u[3] = {(v & 1) ? 1.0 : -1.0, (v & 2) ? 1.0 : -1.0, (v & 4) ? 1.0 : -1.0};
+        double w[3], c3[3];
+        for (int r = 0; r < 3; ++r) w[r] = fwd[4 * r] * u[0] + fwd[4 * r + 1] * u[1] + fwd[4 * r + 2] * u[2] + fwd[4 * r + 3];
+        for (int r = 0; r < 3; ++r) {
+          cur->sph_world[24 * (size_t)i + 3 * v + r] = w[r];
+          ok = ok && std::isfinite(w[r]);
+          c3[r] = view_s[4 * r] * w[0] + view_s[4 * r + 1] * w[1] + view_s[4 * r + 2] * w[2] + view_s[4 * r + 3];
+        }
+        const bool in_front = c3[2] < -1e-6; /* NaN: a corner beside or behind the camera, the box has no pixel rectangle */
+        cur->sph_xy[16 * (size_t)i + 2 * v] = in_front ? (sc->camera.half_width - c3[0] / -c3[2]) / sc->camera.pixel_size : NAN;
+        cur->sph_xy[16 * (size_t)i + 2 * v + 1] = in_front ? (sc->camera.half_height - c3[1] / -c3[2]) / sc->camera.pixel_size : NAN;
+      }
+    }
+    if (!ok) { cur->sph_inv.clear(); cur->sph_norm.clear(); cur->sph_world.clear(); cur->sph_xy.clear(); }
+  }
   cur->box_pad = pad;
   cur->scene_serial++;
   memcpy(d.light_pos, sc->light.position, sizeof d.light_pos);

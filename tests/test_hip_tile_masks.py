@@ -1,6 +1,6 @@
-"""Worlds of at most 64 triangles and no spheres are rendered with two masks per 16 x 16 tile: the triangles a
-camera ray of the tile can hit, and the triangles that can stand between those and the light (built on the host by
-conservative rasterisation and plane separation).  A mask that misses a triangle changes pixels, so: random
+"""Worlds of at most 64 triangles and 64 spheres are rendered with masks per 16 x 16 tile: the primitives a
+camera ray of the tile can hit, and the primitives that can stand between those and the light (built on the host by
+conservative rasterisation and plane separation; a sphere counts as the box that holds it).  A mask that misses a triangle changes pixels, so: random
 triangle soups and closed boxes, lights in front, behind, inside and in the plane of things, image sizes that
 are not multiples of the tile, sub-pixel grids and row bands; every image against the CPU oracle, and at a larger
 size against the kernel that keeps the reference's list (no masks, no filter)."""
@@ -104,3 +104,36 @@ def test_masked_kernel_equals_the_list_kernel_at_1080p(hip, seed):
     assert np.array_equal(got, ref) and st.rays == rst.rays
     if seed == 0:  # the masks are in use: without them the camera rays near the soup alone test all 12 triangles each
         assert st.prim_tests < 6 * st.rays_shadow
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_spheres_and_triangles_shadowing_each_other(hip, seed):
+    """Mixed worlds: boxes and loose triangles between spheres of all shapes, among them a floor-like flattened sphere
+    that reaches behind the camera (no pixel rectangle) and, in some, an eye inside a sphere's box (no masks for its
+    tiles).  Lights between, above and inside the bodies."""
+    from raytracer_amd.scene import Mat4, default_material
+
+    rng = np.random.default_rng(300 + seed)
+    b = SceneBuilder()
+    eye = [(0.0, 1.5, -7.0), (4.0, 3.0, -6.0), (0.0, 0.2, -1.2), (-5.0, 2.0, 3.0)][seed % 4]
+    b.set_camera([150, 203][seed % 2], [97, 77][seed % 2], 0.9, eye, (0.0, 0.3, 0.0))
+    b.set_light([(-6.0, 9.0, -7.0), (0.0, 0.6, 0.0), (3.0, 0.4, -1.0), (0.0, 12.0, 0.0)][(seed // 2) % 4], (1.0, 1.0, 1.0))
+    b.add_sphere(Mat4.mul(Mat4.translate(0.0, -1.0, 0.0), Mat4.scale(12.0, 0.02, 12.0)), default_material(color=(0.9, 0.8, 0.7), reflective=0.3 if seed % 3 == 0 else 0.0))
+    for k in range(int(rng.integers(2, 9))):
+        t = Mat4.mul(Mat4.translate(*rng.uniform(-2.5, 2.5, 3)), Mat4.mul(Mat4.rotate_z(rng.uniform(0, 3)), Mat4.scale(*rng.uniform(0.2, 1.4, 3))))
+        b.add_sphere(t, default_material(color=rng.uniform(0.1, 1.0, 3), shininess=200.0))
+    tris = [soup(rng, int(rng.integers(1, 20)))]
+    for k in range(int(rng.integers(0, 3))):
+        lo = rng.uniform(-2.5, 1.5, 3)
+        tris.append(_box_triangles(tuple(lo), tuple(lo + rng.uniform(0.3, 1.2, 3))))
+    b.add_triangles_f32(np.concatenate(tris))
+    s = b.finish(4)
+    assert s.n_tris <= 64 and s.n_spheres >= 3
+    hip.upload(s)
+    got, st = hip.render_f64(accel=BRUTE, count_rays=True)
+    want, ost = O.render_f64(s)
+    assert st.rays == ost.rays
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)  # the last bits of pow() may differ, a wrong hit would not be that small
+    full, _ = hip.render(accel=BRUTE)
+    ref, _ = hip.render(accel=REFERENCE)
+    assert np.array_equal(full, ref)
