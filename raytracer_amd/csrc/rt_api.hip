@@ -18,12 +18,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "rt_kernels.hip.inc"
 #include "rt_general.hip.inc"
 #include "rt_ppm.hip.inc"
 #include "rt_lbvh.hip.inc"
+#include "rt_sort.h"
 
 /* Scratch of rt_hip_format_ppm_device_noalloc: the text length of every chunk of PPM_CHUNK pixels, then of every
  * group of chunks.  One copy per GPU, held until the process ends (256 KiB); its address on a device comes from
@@ -256,6 +258,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision forms: four workgroups still fit a CU */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
+constexpr int kShadowBlock = 4;            /* shadow masks are worked out per block of this many tiles squared */
 constexpr int kMaxCoverTris = 1 << 16;     /* meshes up to this size are rasterised into the tile grid to find the tiles they cover */
 constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
@@ -715,14 +718,31 @@ int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStre
     for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
     const double pad = 8.0 * RT_EPSILON + 1e-9 * reach;
     const unsigned long long all_tri = nt >= 64 ? ~0ull : (1ull << nt) - 1ull, all_sph = ns >= 64 ? ~0ull : (1ull << ns) - 1ull;
+    /* the shadow masks are worked out for blocks of kShadowBlock x kShadowBlock tiles (what any tile of the block
+     * sees, the pyramid of the whole block): a sixteenth of the work for masks that are hardly any wider */
+    const int bx_n = (tiles_x + kShadowBlock - 1) / kShadowBlock, by_n = (tiles_y + kShadowBlock - 1) / kShadowBlock;
+    std::vector<unsigned long long> block_tri((size_t)bx_n * by_n, all_tri), block_sph((size_t)bx_n * by_n, all_sph);
+    if (cur->shadow_masks)
+      for (int by = 0; by < by_n; ++by)
+        for (int bx = 0; bx < bx_n; ++bx) {
+          const int tx0 = bx * kShadowBlock, tx1 = std::min(tiles_x, tx0 + kShadowBlock), ty0 = by * kShadowBlock, ty1 = std::min(tiles_y, ty0 + kShadowBlock);
+          unsigned long long seen_tri = 0ull, seen_sph = 0ull;
+          int ylo = 1 << 30, yhi = -1;
+          for (int ty = ty0; ty < ty1; ++ty) {
+            ylo = std::min(ylo, y_lo[ty]);
+            yhi = std::max(yhi, y_hi[ty]);
+            for (int tx = tx0; tx < tx1; ++tx) { seen_tri |= tri_mask[(size_t)ty * tiles_x + tx]; seen_sph |= sph_mask[(size_t)ty * tiles_x + tx]; }
+          }
+          unsigned long long bt = 0ull, bs = 0ull;
+          shadow_blockers(tx0 * (double)RT_TILE_W - margin, (double)ylo - margin, tx1 * (double)RT_TILE_W + margin, (double)yhi + 1.0 + margin, seen_tri,
+                          seen_sph, pad, bt, bs);
+          block_tri[(size_t)by * bx_n + bx] = bt;
+          block_sph[(size_t)by * bx_n + bx] = bs;
+        }
     for (int e = 0; e < plan->entries; ++e) {
       const int tile = list[e], tx = tile % tiles_x, ty = tile / tiles_x;
-      unsigned long long m[4] = {tri_mask[tile], all_tri, sph_mask[tile], all_sph};
-      if (cur->shadow_masks) {
-        m[1] = m[3] = 0ull;
-        shadow_blockers(tx * (double)RT_TILE_W - margin, (double)y_lo[ty] - margin, (tx + 1) * (double)RT_TILE_W + margin,
-                        (double)y_hi[ty] + 1.0 + margin, m[0], m[2], pad, m[1], m[3]);
-      }
+      const size_t blk = (size_t)(ty / kShadowBlock) * bx_n + tx / kShadowBlock;
+      const unsigned long long m[4] = {tri_mask[tile], block_tri[blk], sph_mask[tile], block_sph[blk]};
       for (int k = 0; k < 4; ++k) {
         list.push_back((int32_t)(m[k] & 0xffffffffull));
         list.push_back((int32_t)(m[k] >> 32));
@@ -919,17 +939,29 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       for (double v : cur->tri_world) reach = std::fmax(reach, std::fabs(v));
       for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
       const double pad = 8.0 * RT_EPSILON + 1e-9 * reach;
+      /* the shadow masks are worked out for blocks of kShadowBlock x kShadowBlock tiles (what any tile of the block
+       * sees, the pyramid of the whole block): a sixteenth of the work for masks that are hardly any wider */
+      const unsigned long long all = cur->scene.n_tris >= 64 ? ~0ull : (1ull << cur->scene.n_tris) - 1ull;
+      const int bx_n = (tiles_x + kShadowBlock - 1) / kShadowBlock, by_n = (tiles_y + kShadowBlock - 1) / kShadowBlock;
+      std::vector<unsigned long long> block_mask((size_t)bx_n * by_n, all);
+      if (cur->shadow_masks && !cur->tri_world.empty())
+        for (int by = 0; by < by_n; ++by)
+          for (int bx = 0; bx < bx_n; ++bx) {
+            const int tx0 = bx * kShadowBlock, tx1 = std::min(tiles_x, tx0 + kShadowBlock), ty0 = by * kShadowBlock, ty1 = std::min(tiles_y, ty0 + kShadowBlock);
+            unsigned long long seen = 0ull, sh = 0ull, none = 0ull;
+            int ylo = 1 << 30, yhi = -1;
+            for (int ty = ty0; ty < ty1; ++ty) {
+              ylo = std::min(ylo, y_lo[ty]);
+              yhi = std::max(yhi, y_hi[ty]);
+              for (int tx = tx0; tx < tx1; ++tx) seen |= masks[(size_t)ty * tiles_x + tx];
+            }
+            /* the same two pixels of margin as the rasterisation that made the masks */
+            if (seen) shadow_blockers(tx0 * (double)RT_TILE_W - 2.0, (double)ylo - 2.0, tx1 * (double)RT_TILE_W + 2.0, (double)yhi + 3.0, seen, 0ull, pad, sh, none);
+            block_mask[(size_t)by * bx_n + bx] = sh;
+          }
       for (int e = 0; e < plan->entries; ++e) {
         const int tile = heavy[e] & RT_TILE_MASK, tx = tile % tiles_x, ty = tile / tiles_x;
-        const unsigned long long m = masks[(size_t)tile];
-        /* the same two pixels of margin as the rasterisation that made m */
-        const unsigned long long all = cur->scene.n_tris >= 64 ? ~0ull : (1ull << cur->scene.n_tris) - 1ull;
-        unsigned long long sh = all, none = 0ull;
-        if (m != 0ull && cur->shadow_masks && !cur->tri_world.empty()) {
-          sh = 0ull;
-          shadow_blockers(tx * (double)RT_TILE_W - 2.0, (double)y_lo[ty] - 2.0, (tx + 1) * (double)RT_TILE_W + 2.0, (double)y_hi[ty] + 3.0, m,
-                          0ull, pad, sh, none);
-        }
+        const unsigned long long m = masks[(size_t)tile], sh = block_mask[(size_t)(ty / kShadowBlock) * bx_n + tx / kShadowBlock];
         heavy.push_back((int32_t)(m & 0xffffffffull));
         heavy.push_back((int32_t)(m >> 32));
         heavy.push_back((int32_t)(sh & 0xffffffffull));
@@ -1566,6 +1598,41 @@ bool rccl_ok(ncclResult_t r, const char* what) {
     if (!rccl_ok((call), #call)) return RT_ERR_HIP; \
   } while (0)
 
+/* librt_hip_sort.so (rt_sort.h), looked for beside this library first */
+struct SortLib {
+  void* lib = nullptr;
+  decltype(&rt_sort_pairs_u64_u32) pairs = nullptr;
+  decltype(&rt_exclusive_sum_u32) sum = nullptr;
+};
+SortLib g_sort;
+int load_sort() {
+  if (g_sort.lib) return RT_OK;
+  void* lib = nullptr;
+  Dl_info here;
+  if (dladdr((const void*)&rt_hip_strerror, &here) && here.dli_fname) {
+    std::string path(here.dli_fname);
+    const size_t slash = path.rfind('/');
+    path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "librt_hip_sort.so";
+    lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!lib) lib = dlopen("librt_hip_sort.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) {
+    snprintf(g_err, sizeof g_err, "the device BVH build needs librt_hip_sort.so beside librt_hip.so: %s", dlerror());
+    return RT_ERR_UNSUPPORTED;
+  }
+  SortLib l;
+  l.lib = lib;
+  l.pairs = (decltype(l.pairs))dlsym(lib, "rt_sort_pairs_u64_u32");
+  l.sum = (decltype(l.sum))dlsym(lib, "rt_exclusive_sum_u32");
+  if (!l.pairs || !l.sum) {
+    snprintf(g_err, sizeof g_err, "librt_hip_sort.so lacks rt_sort_pairs_u64_u32 / rt_exclusive_sum_u32");
+    dlclose(lib);
+    return RT_ERR_UNSUPPORTED;
+  }
+  g_sort = l;
+  return RT_OK;
+}
+
 int load_rccl() {
   if (g_rccl.lib) return RT_OK;
   void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -2071,6 +2138,10 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   const int n = cur->scene.n_tris;
   if (n >= (1 << 27)) return RT_ERR_TOO_LARGE;
   if (info) memset(info, 0, sizeof *info);
+  {
+    const int src = load_sort();
+    if (src != RT_OK) return src;
+  }
   if (n <= leaf_size) { /* nothing to walk: the exhaustive loop is the walk */
     if (cur->d_bvh) (void)hipFree(cur->d_bvh);
     cur->d_bvh = nullptr;
@@ -2091,9 +2162,8 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   const size_t nn = (size_t)n, ni = nn - 1;
   if (!b.get(&tris_out, nn) || !b.get(&trif_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
   size_t sort_bytes = 0, scan_bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63, cur->stream));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int)ni, cur->stream));
+  HIP_TRY((hipError_t)g_sort.pairs(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, n, cur->stream));
+  HIP_TRY((hipError_t)g_sort.sum(nullptr, &scan_bytes, nullptr, nullptr, (int)ni, cur->stream));
   const size_t space_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes; /* both library calls work in it, in turn */
   size_t arena_bytes = 0;
   auto reserve = [&](size_t bytes) { const size_t at = arena_bytes; arena_bytes += (bytes + 255) & ~(size_t)255; return at; };
@@ -2139,7 +2209,7 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   if (e == hipSuccess) {
     hipLaunchKernelGGL(lbvh_keys_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)cur->d_tris, n, cur->mesh_lo[0], cur->mesh_lo[1],
                        cur->mesh_lo[2], scale[0], scale[1], scale[2], keys, index);
-    e = hipcub::DeviceRadixSort::SortPairs(sort_space, sort_bytes, keys, keys_sorted, index, index_sorted, n, 0, 63, s);
+    e = (hipError_t)g_sort.pairs(sort_space, &sort_bytes, keys, keys_sorted, index, index_sorted, n, s);
   }
   if (e == hipSuccess) {
     hipLaunchKernelGGL(lbvh_gather_kernel, per_tri, dim3(LBVH_THREADS), 0, s, (const DevTri*)cur->d_tris,
@@ -2151,7 +2221,7 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   }
   if (e == hipSuccess) {
     size_t bytes = space_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(sort_space, bytes, walked, slot, (int)ni, s);
+    e = (hipError_t)g_sort.sum(sort_space, &bytes, walked, slot, (int)ni, s);
   }
   if (e == hipSuccess) {
     hipLaunchKernelGGL(lbvh_fit_kernel, dim3((unsigned)((nn + LBVH_FIT_THREADS - 1) / LBVH_FIT_THREADS)), dim3(LBVH_FIT_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,

@@ -33,6 +33,15 @@ def test_hip_library_exports_every_declared_symbol():
     assert set(names) <= exported
 
 
+def test_sort_library_is_separate_and_the_main_library_small():
+    """The sort and scan of the device BVH build (hundreds of library kernels) live in librt_hip_sort.so, which
+    librt_hip.so loads on demand; what every process loads at start-up stays under 2 MiB."""
+    sort = os.path.join(_ffi.LIB_DIR, "librt_hip_sort.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", sort], capture_output=True, text=True, check=True).stdout
+    assert {"rt_sort_pairs_u64_u32", "rt_exclusive_sum_u32"} <= set(re.findall(r" T (rt_\w+)", out))
+    assert os.path.getsize(os.path.join(_ffi.LIB_DIR, "librt_hip.so")) < 2 * 1024 * 1024
+
+
 def test_host_library_exports_every_declared_symbol():
     L = _ffi.host_lib()
     for n in declared_functions("rt_scene.h"):
