@@ -59,10 +59,19 @@ CLI = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer_hip")
 
 
 def git_commit():
+    """The commit of this tree: from git where the tree is a checkout, else from the note build() leaves beside the
+    libraries (the tree that runs on the GPU box is a copy without .git)."""
     try:
         out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
-        return out.stdout.strip() or None
+        if out.returncode == 0 and out.stdout.strip():
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
+                                   timeout=10).stdout.strip()
+            return out.stdout.strip() + ("+local changes" if dirty else "")
     except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        return open(os.path.join(ROOT, "raytracer_amd", "lib", "BUILD_COMMIT")).read().strip() or None
+    except OSError:
         return None
 
 
