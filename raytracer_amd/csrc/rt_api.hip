@@ -51,6 +51,15 @@ struct Context {
   bool sphere_masks = true; /* worlds with up to 64 spheres: masks for them as well */
   bool shadow_masks = true; /* ... and their shadow rays only the triangles that can lie between those and the light */
   bool tile_masks = true;   /* meshes of up to 64 triangles: camera rays test only the triangles that cover their tile */
+  bool tile_lists = true;   /* larger meshes walked exhaustively: per-tile lists of those triangles instead of masks */
+  bool list_lds = true;     /* a mesh tile's workgroup copies its list to LDS (false: read through scalar loads) */
+  /* Launches that walk a tree: the camera rays of a tile with at most this many triangles in its list run down the list
+   * instead (0: never).  A launch of many mesh tiles is bound by throughput, and the list costs less work than the walk
+   * up to a few hundred triangles (4K lighthouse 80 -> 65 us).  A launch whose mesh tiles are all resident at once lasts
+   * as long as its slowest wave, which sits in the most crowded tile: there a long list takes as long as the walk
+   * (about 300 cycles per triangle of the list against 70 node steps and 16 leaves), so only the short ones are used
+   * (1080p lighthouse 57.5 us with no lists, 52 with lists of up to 64, 55.7 up to 128, 58 up to 256). */
+  int list_max_walk = 256, list_max_walk_few = 64;
   bool cover_tiles = true;  /* find the mesh tiles by rasterising the triangles (false: by the rectangle of the mesh's bounds) */
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
@@ -84,6 +93,11 @@ struct Context {
    * and as the camera sees them (pixels; NaN: a corner beside or behind the camera) */
   std::vector<double> sph_inv, sph_norm, sph_world, sph_xy;
   double host_light[3] = {0, 0, 0};
+  std::vector<DevTriF> host_trif; /* meshes of up to kMaxListTris triangles without spheres: the single-precision forms as
+                                     uploaded (the per-tile lists of plan_tiles hold copies of them) */
+  std::vector<int32_t> host_tri_order; /* with host_trif: every triangle's position in the world's object list (the tie-break of hit()) */
+  std::vector<float> host_tri_k;  /* with host_trif: (p1 - camera origin) . (e2 x e1) of every triangle (the numerator of t for a camera ray) */
+  std::vector<float> tri_depth;   /* with tri_xy: how far in front of the camera the nearest corner of every triangle lies */
   std::vector<double> tri_xy;  /* where the camera sees the three corners of every triangle (x y x y x y, in pixels, pixel
                                   k covering [k, k + 1)); empty: unknown, or a corner beside or behind the camera */
   /* tile orders of recent launches and the parameters each was made for (scene, bands, kernel family, overlap
@@ -95,6 +109,10 @@ struct Context {
     int heavy = 0, tiles = 0, entries = 0;
     bool light_background = false; /* the light tiles lie outside the mesh's pixel rectangle */
     int light_per_block = 1;       /* light tiles per workgroup */
+    size_t list_forms = 0, list_total = 0; /* RenderArgs.list_forms / list_total of launches with this plan (0: no lists) */
+    std::vector<std::vector<int32_t>> tile_tris; /* by tile number: the triangles of its list (kept while refinements are pending) */
+    int list_max = 0;                            /* tiles with longer lists have none (walks only) */
+    int list_longest = 0;                        /* the longest list of a mesh tile */
     size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
                                       ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
@@ -259,6 +277,9 @@ constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kShadowBlock = 4;            /* shadow masks are worked out per block of this many tiles squared */
+constexpr int kMaxLdsListForms = 384;      /* a mesh tile's workgroup keeps a list of up to this many forms in LDS (24 KiB) */
+constexpr int kMaxListTris = 1 << 16;      /* meshes up to this size get per-tile triangle lists for their camera rays ... */
+constexpr size_t kMaxListEntries = 1 << 20; /* ... unless the lists of a launch would hold more than this many forms (64 MiB) */
 constexpr int kMaxCoverTris = 1 << 16;     /* meshes up to this size are rasterised into the tile grid to find the tiles they cover */
 constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
@@ -291,22 +312,33 @@ void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStre
   } else if (stage == 1) {
     launch_kind<false, REFLECT, 1>(kind, lds, grid, s, a, rgb, canvas);
   } else {
-    launch_kind<false, REFLECT, 0>(kind, 0, grid, s, a, rgb, canvas);
+    launch_kind<false, REFLECT, 0>(kind, lds, grid, s, a, rgb, canvas);
   }
 }
-void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb,
+void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a_in, unsigned char* rgb,
             double* canvas) {
+  RenderArgs a = a_in;
+  const size_t per_form = sizeof(DevTriF) + 12; /* a form, its numerator, its triangle's number and list position */
+  const size_t list_bytes = (size_t)a.list_lds * per_form;
   /* The counting build exists once per family: what it counts (rays, tests) does not depend on where the
    * primitives are staged, on the kinds present or on whether any material reflects. */
   if (count) {
-    if (bvh) launch_one<true, true, true, 0, 0>(0, grid, s, a, rgb, canvas);
-    else launch_one<true, false, true, 0, 0>(0, grid, s, a, rgb, canvas);
+    if (bvh) {
+      a.list_lds = 0; /* built for both kinds of primitives: camera rays walk the tree */
+      launch_one<true, true, true, 0, 0>(0, grid, s, a, rgb, canvas);
+    } else {
+      launch_one<true, false, true, 0, 0>(list_bytes, grid, s, a, rgb, canvas);
+    }
     return;
   }
   int stage = 0;
   size_t lds = 0;
   if (cur->use_lds) {
-    if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
+    if (!bvh && a.list_forms) {
+      stage = 0; /* camera rays read their tile's list (from the workgroup's copy in LDS if it fits), the others the whole
+                    array through scalar loads */
+      lds = list_bytes;
+    } else if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
       stage = 1;
       lds = (size_t)cur->scene.n_tris * sizeof(DevTriF);
     } else if (bvh && cur->lds_stack && cur->scene.bvh_depth >= 1) {
@@ -317,15 +349,21 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
       if (cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
         stage = 3;
         lds = nodes + stacks;
+        a.list_lds = std::min(a.list_lds, (int)((kMaxLdsPerWorkgroup - lds) / per_form / 4 * 4)); /* longer lists are read from memory */
+        lds += (size_t)a.list_lds * per_form;
       } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3)) {
         /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
          * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
          * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
         stage = 4;
         lds = stacks;
+        a.list_lds = std::min(a.list_lds, (int)(((reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3) - lds) / per_form / 4 * 4));
+        lds += (size_t)a.list_lds * per_form;
       }
     }
   }
+  if (bvh && stage == 0) a.list_lds = 0;
+  if (!cur->use_lds) a.list_lds = 0;
   const int kind = (!bvh && cur->scene.n_tris == 0) ? 1 : (cur->scene.n_spheres == 0 ? 2 : 0);
   if (reflect) launch_family<true>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
   else launch_family<false>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
@@ -420,12 +458,14 @@ int store_plan(Context::TilePlan* t, const long long key[6], const std::vector<i
  * triangles that cover it only (`masks`).  y_lo / y_hi: the image rows of every tile row (bands make them differ
  * from the packed rows).  false: unknown. */
 bool covered_tiles(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const std::vector<int>& y_hi, bool rows_are_y,
-                   std::vector<unsigned char>& cover, std::vector<unsigned long long>* masks) {
+                   std::vector<unsigned char>& cover, std::vector<unsigned long long>* masks,
+                   std::vector<std::vector<int32_t>>* lists = nullptr) {
   if (cur->tri_xy.empty()) return false;
   const double margin = 2.0;
   cover.assign((size_t)tiles_x * tiles_y, 0);
   const size_t nt = cur->tri_xy.size() / 6;
   if (masks) masks->assign((size_t)tiles_x * tiles_y, 0ull); /* bit k of a tile: triangle k may be seen through it (nt <= 64) */
+  if (lists) lists->assign((size_t)tiles_x * tiles_y, std::vector<int32_t>()); /* the same as lists of triangle numbers */
   for (size_t k = 0; k < nt; ++k) {
     const double* q = &cur->tri_xy[6 * k];
     double bx0 = std::fmin(q[0], std::fmin(q[2], q[4])) - margin, bx1 = std::fmax(q[0], std::fmax(q[2], q[4])) + margin;
@@ -448,7 +488,7 @@ bool covered_tiles(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const
       const double ylo = (double)y_lo[ty] - margin, yhi = (double)y_hi[ty] + 1.0 + margin;
       for (int tx = tx0; tx <= tx1; ++tx) {
         unsigned char& c = cover[(size_t)ty * tiles_x + tx];
-        if (c && !masks) continue;
+        if (c && !masks && !lists) continue;
         bool out = false;
         if (edges) {
           const double xlo = (double)tx * RT_TILE_W - margin, xhi = (double)(tx + 1) * RT_TILE_W + margin;
@@ -463,10 +503,16 @@ bool covered_tiles(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const
         if (!out) {
           c = 1;
           if (masks) (*masks)[(size_t)ty * tiles_x + tx] |= 1ull << k;
+          if (lists) (*lists)[(size_t)ty * tiles_x + tx].push_back((int32_t)k);
         }
       }
     }
   }
+  /* nearest first (by the nearest corner): a ray that has its hit early can leave most of what lies behind it to the
+   * single-precision test (list_nearest); the order decides nothing else */
+  if (lists && cur->tri_depth.size() == nt)
+    for (std::vector<int32_t>& l : *lists)
+      std::stable_sort(l.begin(), l.end(), [](int32_t a_, int32_t b_) { return cur->tri_depth[(size_t)a_] < cur->tri_depth[(size_t)b_]; });
   return true;
 }
 
@@ -647,6 +693,72 @@ void shadow_blockers(double x0, double y0, double x1, double y1, unsigned long l
   }
 }
 
+/* Behind the `entries` entries of `list`: four 64-bit words per entry, as for the masks, of which the first says where
+ * the tile's triangles start in the arrays that follow (low half) and how many they are (high half; all ones: the
+ * tile has more than max_per_tile and gets no list); then, from a 64-byte boundary on, copies of those triangles'
+ * single-precision forms, tile after tile in the order of their first entry (the parts of a split tile share one
+ * copy), so that a tile's camera rays read consecutive memory; then the numbers of the same triangles; then, for each,
+ * the numerator of a camera ray's t (host_tri_k); then their positions in the world's object list.
+ * false: nothing appended (no triangles at all, or more than kMaxListEntries forms). */
+bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vector<std::vector<int32_t>>& tile_tris, int max_per_tile,
+                       Context::TilePlan* plan) {
+  std::vector<long long> start(tile_tris.size(), -1);
+  size_t total = 0;
+  for (int e = 0; e < entries; ++e) {
+    const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+    if (tile >= tile_tris.size()) return false;
+    if (start[tile] >= 0 || tile_tris[tile].size() > (size_t)max_per_tile) continue;
+    start[tile] = (long long)total;
+    total += tile_tris[tile].size();
+  }
+  plan->mask_offset = 0;
+  plan->list_forms = 0;
+  plan->list_total = 0;
+  plan->list_max = max_per_tile;
+  plan->list_longest = 0;
+  if (total == 0 || total > kMaxListEntries) return false;
+  for (int e = 0; e < plan->heavy && e < entries; ++e) {
+    const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+    if (start[tile] >= 0) plan->list_longest = std::max(plan->list_longest, (int)tile_tris[tile].size());
+  }
+  if (getenv("RT_HIP_VERBOSE")) {
+    int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0};
+    for (int e = 0; e < plan->heavy && e < entries; ++e) {
+      const int n = (int)tile_tris[(size_t)(list[e] & RT_TILE_MASK)].size();
+      longest_any = std::max(longest_any, n);
+      n_over[n > 512 ? 4 : (n > 256 ? 3 : (n > 128 ? 2 : (n > 64 ? 1 : 0)))]++;
+    }
+    fprintf(stderr, "tile lists: %zu forms, longest list in use %d (of any mesh tile: %d), mesh entries with <=64/128/256/512/more: %d %d %d %d %d\n",
+            total, plan->list_longest, longest_any, n_over[0], n_over[1], n_over[2], n_over[3], n_over[4]);
+  }
+  list.resize((size_t)entries);
+  if (list.size() % 2) list.push_back(0);
+  plan->mask_offset = list.size();
+  for (int e = 0; e < entries; ++e) {
+    const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+    const bool has = start[tile] >= 0;
+    list.push_back(has ? (int32_t)(uint32_t)start[tile] : 0);
+    list.push_back(has ? (int32_t)tile_tris[tile].size() : -1);
+    for (int k = 0; k < 6; ++k) list.push_back(0);
+  }
+  while (list.size() % 16) list.push_back(0);
+  plan->list_forms = list.size();
+  plan->list_total = total;
+  const size_t words = sizeof(DevTriF) / 4;
+  list.resize(plan->list_forms + total * words + 3 * total, 0);
+  for (size_t tile = 0; tile < tile_tris.size(); ++tile) {
+    if (start[tile] < 0) continue;
+    const std::vector<int32_t>& l = tile_tris[tile];
+    for (size_t k = 0; k < l.size(); ++k) {
+      memcpy(&list[plan->list_forms + ((size_t)start[tile] + k) * words], &cur->host_trif[(size_t)l[k]], sizeof(DevTriF));
+      list[plan->list_forms + total * words + (size_t)start[tile] + k] = l[k];
+      memcpy(&list[plan->list_forms + total * words + total + (size_t)start[tile] + k], &cur->host_tri_k[(size_t)l[k]], sizeof(float));
+      list[plan->list_forms + total * words + 2 * total + (size_t)start[tile] + k] = cur->host_tri_order[(size_t)l[k]];
+    }
+  }
+  return true;
+}
+
 /* Workgroups of a launch with `plan`: one per mesh entry, then the light tiles, light_per_block to a workgroup. */
 int plan_blocks(const Context::TilePlan* plan) {
   return plan->heavy + (plan->entries - plan->heavy + plan->light_per_block - 1) / plan->light_per_block;
@@ -758,6 +870,9 @@ int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStre
   a.light_per_block = plan->light_per_block;
   a.n_entries = plan->entries;
   a.light_is_background = plan->light_background ? 1 : 0;
+  a.list_forms = 0;
+  a.list_total = 0;
+  a.list_lds = 0;
   n_blocks = plan_blocks(plan);
   return RT_OK;
 }
@@ -775,6 +890,9 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.light_per_block = 1;
   a.n_entries = 0;
   a.light_is_background = 0;
+  a.list_forms = 0;
+  a.list_total = 0;
+  a.list_lds = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
   if (masked_world(bvh) && cur->light_per_block > 1) {
@@ -809,8 +927,13 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     std::vector<unsigned char> cover;
     std::vector<unsigned long long> masks;
     const bool want_masks = !bvh && cur->tile_masks && cur->scene.n_tris <= 64;
+    std::vector<std::vector<int32_t>> tri_lists;
+    bool want_lists = cur->tile_lists && (bvh ? cur->list_max_walk > 0 || cur->list_max_walk_few > 0 : cur->scene.n_tris > 64) &&
+                      cur->host_trif.size() == (size_t)cur->scene.n_tris && cur->host_tri_k.size() == cur->host_trif.size() &&
+                      cur->host_tri_order.size() == cur->host_trif.size();
     const bool have_cover = have_rect && cur->cover_tiles &&
-                            covered_tiles(tiles_x, tiles_y, y_lo, y_hi, p->n_ranks <= 1, cover, want_masks ? &masks : nullptr);
+                            covered_tiles(tiles_x, tiles_y, y_lo, y_hi, p->n_ranks <= 1, cover, want_masks ? &masks : nullptr,
+                                          want_lists ? &tri_lists : nullptr);
     for (int ty = 0; ty < tiles_y; ++ty) {
       const bool row_hit = !have_rect || (y_hi[ty] >= y0 && y_lo[ty] <= y1);
       for (int tx = 0; tx < tiles_x; ++tx) {
@@ -931,7 +1054,18 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     heavy.insert(heavy.end(), light.begin(), light.end());
     plan->entries = (int)heavy.size();
     plan->mask_offset = 0;
-    if (have_cover && want_masks) {
+    plan->list_forms = 0;
+    plan->list_total = 0;
+    std::vector<int32_t> entries_only;
+    if (have_cover && want_lists) {
+      entries_only = heavy;
+      const bool few_tiles = (size_t)plan->heavy <= (size_t)(cur->split_max_per_cu + 2) * cur->n_cu && !overlap;
+      if (!append_tile_lists(heavy, plan->entries, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan))
+        want_lists = false;
+    }
+    if (have_cover && want_lists) {
+      plan->tile_tris.swap(tri_lists);
+    } else if (have_cover && want_masks) {
       /* behind the entries (8-byte aligned): for every entry the triangles its camera rays have to be tested against */
       if (heavy.size() % 2) heavy.push_back(0);
       plan->mask_offset = heavy.size();
@@ -971,8 +1105,9 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     }
     const int src = store_plan(plan, key, heavy, s);
     if (src != RT_OK) return src;
-    if (plan->refine_left > 0) plan->host_list = heavy;
+    if (plan->refine_left > 0) plan->host_list = entries_only.empty() ? heavy : entries_only;
     else plan->host_list.clear();
+    if (plan->refine_left <= 0 || !plan->list_forms) { plan->tile_tris.clear(); plan->tile_tris.shrink_to_fit(); }
   }
   cur->launch_plan = plan;
   cur->launch_tile_list = plan->d_list;
@@ -981,6 +1116,9 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.light_per_block = plan->light_per_block;
   a.n_entries = plan->entries;
   a.light_is_background = plan->light_background ? 1 : 0;
+  a.list_forms = (int32_t)plan->list_forms;
+  a.list_total = (int32_t)plan->list_total;
+  a.list_lds = plan->list_forms && cur->list_lds ? (std::min(plan->list_longest, kMaxLdsListForms) + 3) / 4 * 4 : 0;
   n_blocks = plan_blocks(plan);
   return RT_OK;
 }
@@ -1287,12 +1425,22 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   float best_ms = 1e30f;
   bool current_is_best = true;
   int rc = RT_OK;
+  const bool with_lists = plan->list_forms != 0 && !plan->tile_tris.empty();
   auto adopt = [&](const std::vector<int32_t>& l) {
-    const int src = store_plan(plan, key, l, s);
+    std::vector<int32_t> full;
+    if (with_lists) { /* the entries changed: so do the words behind them that say where each entry's triangle list lies */
+      full = l;
+      if (!append_tile_lists(full, (int)l.size(), plan->tile_tris, plan->list_max, plan)) return (int)RT_ERR_INVALID;
+    }
+    const int src = store_plan(plan, key, with_lists ? full : l, s);
     if (src != RT_OK) return src;
     plan->heavy = (int)l.size() - n_light;
     plan->entries = (int)l.size();
     cur->launch_tile_list = plan->d_list;
+    cur->launch_tile_mask = plan->mask_offset ? reinterpret_cast<const unsigned long long*>(plan->d_list + plan->mask_offset) : nullptr;
+    a.list_forms = (int32_t)plan->list_forms;
+    a.list_total = (int32_t)plan->list_total;
+    a.list_lds = plan->list_forms && cur->list_lds ? (std::min(plan->list_longest, kMaxLdsListForms) + 3) / 4 * 4 : 0;
     a.n_heavy = plan->heavy;
     a.n_entries = plan->entries;
     n_blocks = plan_blocks(plan);
@@ -1374,6 +1522,8 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     current_is_best = false;
   }
   if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
+  plan->tile_tris.clear();
+  plan->tile_tris.shrink_to_fit();
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return rc;
@@ -1412,6 +1562,9 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
           a.ablate = 0; /* the timing cuts are the fast kernels'; this kernel reads the field as "probe launch" */
       a.n_entries = 0;
       a.light_is_background = 0;
+      a.list_forms = 0;
+      a.list_total = 0;
+      a.list_lds = 0;
       n_blocks = (int)n_tiles;
       bvh = false;
       const int prc = plan_general_tiles(p, rows, s, a);
@@ -1743,6 +1896,9 @@ int create_context(int device) {
   }
   if (const char* e = getenv("RT_HIP_COVER_TILES")) cur->cover_tiles = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_MASKS")) cur->tile_masks = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_TILE_LISTS")) cur->tile_lists = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_LIST_MAX_WALK")) cur->list_max_walk = cur->list_max_walk_few = atoi(e);
+  if (const char* e = getenv("RT_HIP_LIST_LDS")) cur->list_lds = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SHADOW_MASKS")) cur->shadow_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SPHERE_MASKS")) cur->sphere_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */
@@ -1965,6 +2121,22 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if ((rc = upload(&cur->d_spheres, hs.data(), sizeof(DevSphere) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_tris, ht.data(), sizeof(DevTri) * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_trif, htf.data(), sizeof(DevTriF) * (size_t)nt)) != RT_OK) return rc;
+  cur->host_trif.clear();
+  cur->host_tri_k.clear();
+  cur->host_tri_order.clear();
+  if (ns == 0 && nt > 0 && nt <= kMaxListTris) {
+    cur->host_trif.assign(htf.begin(), htf.begin() + nt);
+    cur->host_tri_k.resize((size_t)nt);
+    cur->host_tri_order.resize((size_t)nt);
+    for (int k = 0; k < nt; ++k) cur->host_tri_order[k] = ht[k].order;
+    for (int k = 0; k < nt; ++k) {
+      const double* p1 = ht[k].p1;
+      const double* e1 = ht[k].e1;
+      const double* e2 = ht[k].e2;
+      const double n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+      cur->host_tri_k[k] = (float)((p1[0] - org[0]) * n[0] + (p1[1] - org[1]) * n[1] + (p1[2] - org[2]) * n[2]);
+    }
+  }
   if ((rc = upload(&cur->d_sphf, hsf.data(), sizeof(DevSphereF) * (size_t)ns)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_normals, hn.data(), sizeof(double) * 3 * (size_t)nt)) != RT_OK) return rc;
   if ((rc = upload(&cur->d_materials, sc->materials, sizeof(rt_material) * (size_t)sc->n_materials)) != RT_OK) return rc;
@@ -2025,11 +2197,13 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   /* where each triangle lands on the image: the tile order of a launch puts crowded tiles first */
   cur->tri_rect.clear();
   cur->tri_xy.clear();
+  cur->tri_depth.clear();
   double view[16];
   if (nt > 0 && nt <= kMaxTilePlanTris && invert4(sc->camera.inv_view, view)) {
     cur->tri_rect.resize(4 * (size_t)nt);
     bool all_in_front = nt <= kMaxCoverTris;
     if (all_in_front) cur->tri_xy.resize(6 * (size_t)nt);
+    cur->tri_depth.assign(all_in_front ? (size_t)nt : 0, 3.0e38f);
     const double W = sc->camera.hsize, H = sc->camera.vsize;
     for (int k = 0; k < nt; ++k) {
       const DevTri& t = ht[k];
@@ -2042,14 +2216,18 @@ int rt_hip_upload_scene(const rt_scene* sc) {
         if (!(c3[2] < -1e-6)) { x0 = 0.f; y0 = 0.f; x1 = (float)W; y1 = (float)H; all_in_front = false; break; } /* beside or behind the camera */
         const double px = (sc->camera.half_width - c3[0] / -c3[2]) / sc->camera.pixel_size;
         const double py = (sc->camera.half_height - c3[1] / -c3[2]) / sc->camera.pixel_size;
-        if (all_in_front) { cur->tri_xy[6 * (size_t)k + 2 * v] = px; cur->tri_xy[6 * (size_t)k + 2 * v + 1] = py; }
+        if (all_in_front) {
+          cur->tri_xy[6 * (size_t)k + 2 * v] = px;
+          cur->tri_xy[6 * (size_t)k + 2 * v + 1] = py;
+          cur->tri_depth[k] = std::fmin(cur->tri_depth[k], (float)-c3[2]);
+        }
         x0 = std::fmin(x0, (float)px); x1 = std::fmax(x1, (float)px);
         y0 = std::fmin(y0, (float)py); y1 = std::fmax(y1, (float)py);
       }
       float* q = &cur->tri_rect[4 * (size_t)k];
       q[0] = x0 - 1.f; q[1] = y0 - 1.f; q[2] = x1 + 1.f; q[3] = y1 + 1.f;
     }
-    if (!all_in_front) cur->tri_xy.clear();
+    if (!all_in_front) { cur->tri_xy.clear(); cur->tri_depth.clear(); }
   }
   cur->tri_world.clear();
   if (nt > 0 && nt <= 64) {
@@ -2263,6 +2441,14 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   cur->scene.n_bvh_nodes = n_walked;
   cur->scene.bvh_depth = depth;
   cur->bvh_single_leaf = false;
+  /* the triangles are in another order now: what the host knows about them by number no longer applies (tile masks
+   * and lists; the pixel rectangles only ever count triangles per tile, whatever their numbers) */
+  cur->tri_xy.clear();
+  cur->tri_world.clear();
+  cur->host_trif.clear();
+  cur->host_tri_k.clear();
+  cur->host_tri_order.clear();
+  cur->tri_depth.clear();
   HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
   cur->scene_serial++;
   if (info) { info->n_nodes = n_walked; info->depth = depth; info->build_ms = ms; }

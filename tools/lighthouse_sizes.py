@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as R
 r = R.HipRenderer(0)
-for name, w, h, tr, K in (("lighthouse 1080p reflective 0.3", 1920, 1080, 0.3, 200), ("lighthouse 4K", 3840, 2160, 0.0, 100), ("lighthouse 4K reflective 0.3", 3840, 2160, 0.3, 50), ("lighthouse 720p", 1280, 720, 0.0, 300)):
+for name, w, h, tr, K in (("lighthouse 1080p", 1920, 1080, 0.0, 300), ("lighthouse 1080p reflective 0.3", 1920, 1080, 0.3, 200), ("lighthouse 4K", 3840, 2160, 0.0, 100), ("lighthouse 4K reflective 0.3", 3840, 2160, 0.3, 50), ("lighthouse 720p", 1280, 720, 0.0, 300)):
     r.upload(R.stock_scene("lighthouse", w, h, tr, 0.0))
     buf = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
     p = R.make_params(accel=R._ffi.RT_ACCEL_BVH)

@@ -22,7 +22,7 @@ def main():
                 ms.append(st2.kernel_ms)
             m = float(np.median(ms))
             print(json.dumps(dict(scene=name, refl=(tr, sr), accel=an, rays=rays, prim_tests=st.prim_tests,
-                                  node_tests=st.node_tests, kernel_ms=round(m, 4), mrays_s=round(rays / m / 1e3, 1))), flush=True)
+                                  node_tests=st.node_tests, tri_exact=st.tri_exact, kernel_ms=round(m, 4), mrays_s=round(rays / m / 1e3, 1))), flush=True)
     r.shutdown()
 
 main()

@@ -46,6 +46,11 @@ if WORDS > 6:  # -DRT_PHASES=1: shader-clock ticks per phase, summed over the he
     tot = ph.sum()
     print("phases of heavy waves (share of their ticks; median ticks per wave):",
           [(names[k], round(float(ph[:, k].sum() / tot), 3), int(np.median(ph[:, k]))) for k in range(7)])
+if WORDS > 6:  # the waves that end last: where their ticks went
+    order = np.argsort(-end_us)[:6]
+    for i in order:
+        print(f"  wave ending at {end_us[i]:.2f} us (started {start_us[i]:.2f}, heavy {int(s[i, 5])}): ticks per phase",
+              [int(x) for x in s[i, 6:13]])
 print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
 hist, edges = np.histogram(end_us, bins=12)
 print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
