@@ -227,9 +227,10 @@ typedef struct rt_stats {
    *   entry reads as a free slot to add_intersection and the next append overwrites it, RayTracer.c:168.
    * list_cap_rays: rays that appended more than 100 entries (two per sphere with real roots, one per triangle
    *   hit, of either sign of t); the reference drops the appends beyond INTERSECTIONS_SIZE, RayTracer.c:161.
-   *   Exact for camera and reflected rays under RT_ACCEL_BRUTE; a BVH walk and a shadow ray that stops at its
-   *   first blocker see fewer entries than the reference appends, so there the count is a lower bound.  A
-   *   world with 2 * spheres + triangles <= 100 cannot reach the cap at all. */
+   *   Exact for camera and reflected rays under RT_ACCEL_BRUTE (camera rays that run down their tile's list of
+   *   triangles included: the counting kernel evaluates every triangle the ray can hit); a BVH walk and a shadow
+   *   ray that stops at its first blocker see fewer entries than the reference appends, so there the count is a
+   *   lower bound.  A world with 2 * spheres + triangles <= 100 cannot reach the cap at all. */
   uint64_t zero_t_entries;
   uint64_t list_cap_rays;
 } rt_stats;

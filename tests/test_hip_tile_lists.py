@@ -96,3 +96,26 @@ def test_exhaustive_loop_after_the_device_tree_build_reordered_the_triangles(hip
     want, ost = O.render_rgb(s)
     assert np.array_equal(before, want) and np.array_equal(after, want) and np.array_equal(walked, want)
     assert bst.rays == ast.rays == ost.rays
+
+
+def test_counting_build_still_sees_every_entry_of_a_listed_camera_ray(hip):
+    """104 large triangles stacked behind each other: a camera ray through the middle appends 104 entries, of which
+    the reference keeps 100 (RayTracer.c:161).  The plain kernel leaves the 103 behind the first to the
+    single-precision test; the counting kernel evaluates all of them and reports the rays that went over the cap."""
+    from raytracer_amd.scene import SceneBuilder
+
+    tris = np.array([[-3, -3, z, 3, -3, z, 0, 4, z] for z in np.arange(104) * 0.125], dtype=np.float32)
+    b = SceneBuilder()
+    b.set_camera(64, 48, 0.6, (0.0, 0.0, -10.0), (0.0, 0.0, 0.0))
+    b.set_light((-30.0, 0.0, -0.5), (1.0, 1.0, 1.0))  # the lines of the shadow rays pass beside the triangles behind
+    b.add_triangles_f32(tris)
+    s = b.finish(4)
+    hip.upload(s)
+    O.render_rgb(s)
+    assert O.probe().list_overflow > 0
+    got, st = hip.render(accel=BRUTE, count_rays=True)
+    assert st.list_cap_rays > 0 and st.zero_t_entries == 0
+    assert st.tri_exact < st.rays_primary * 2  # ... while it counts the double-precision tests of the plain kernel
+    ref, _ = hip.render(accel=REFERENCE)
+    want, _ = O.render_rgb(s)
+    assert np.array_equal(ref, want)
