@@ -52,6 +52,12 @@ struct Context {
   bool shadow_masks = true; /* ... and their shadow rays only the triangles that can lie between those and the light */
   bool tile_masks = true;   /* meshes of up to 64 triangles: camera rays test only the triangles that cover their tile */
   bool tile_lists = true;   /* larger meshes walked exhaustively: per-tile lists of those triangles instead of masks */
+  bool shadow_lists = true; /* with the camera rays' lists: per block of tiles, the triangles that can lie between what those rays see and the light */
+  /* Frames that walk the tree: shadow rays of a tile with at most this many such triangles would run down the list
+   * instead.  Off: the tiles whose waves a frame waits for have the longest lists (lighthouse 1080p: up to 790 possible
+   * blockers for a block of the lantern room, 140 on average), and those walk in any case; with lists of up to 64 ..
+   * 192 the 1080p frames stay within 1 % and 4K gains 5 %, with lists of up to 320 they take 75 % longer. */
+  int shadow_list_max_walk = 0;
   bool list_lds = true;     /* a mesh tile's workgroup copies its list to LDS (false: read through scalar loads) */
   /* Launches that walk a tree: the camera rays of a tile with at most this many triangles in its list run down the list
    * instead (0: never).  A launch of many mesh tiles is bound by throughput, and the list costs less work than the walk
@@ -88,6 +94,7 @@ struct Context {
   double box_pad = 0.0; /* what every single-precision box is grown by */
   std::vector<float> tri_rect; /* pixel rectangle (x0 y0 x1 y1) of every triangle as the camera sees it; empty: unknown */
   std::vector<double> tri_world; /* meshes of up to 64 triangles: the corners in world space (9 per triangle) */
+  std::vector<double> mesh_world; /* with host_trif (meshes of up to kMaxListTris triangles, no spheres): the same for every triangle */
   /* worlds of up to 64 spheres: rows 0..2 of every inverse transform, its Frobenius norm, and the eight corners of the
    * box that holds the sphere (the image of [-1, 1]^3; corner v has +1 where bit 0 / 1 / 2 of v is set) in world space
    * and as the camera sees them (pixels; NaN: a corner beside or behind the camera) */
@@ -113,6 +120,9 @@ struct Context {
     std::vector<std::vector<int32_t>> tile_tris; /* by tile number: the triangles of its list (kept while refinements are pending) */
     int list_max = 0;                            /* tiles with longer lists have none (walks only) */
     int list_longest = 0;                        /* the longest list of a mesh tile */
+    std::vector<std::vector<int32_t>> tile_shadow; /* by tile number: the triangles of its shadow rays' list (with tile_tris) */
+    std::vector<unsigned char> tile_shadow_ok;     /* by tile number: 1 = tile_shadow holds every possible blocker, 0 = unknown */
+    int shadow_max = 0, shadow_longest = 0;        /* as list_max / list_longest */
     size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
                                       ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
@@ -277,6 +287,7 @@ constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kShadowBlock = 4;            /* shadow masks are worked out per block of this many tiles squared */
+constexpr int kMaxLdsShadowForms = 320;    /* ... and a list of its shadow rays of up to this many (21 KiB) */
 constexpr int kMaxLdsListForms = 384;      /* a mesh tile's workgroup keeps a list of up to this many forms in LDS (24 KiB) */
 constexpr int kMaxListTris = 1 << 16;      /* meshes up to this size get per-tile triangle lists for their camera rays ... */
 constexpr size_t kMaxListEntries = 1 << 20; /* ... unless the lists of a launch would hold more than this many forms (64 MiB) */
@@ -318,13 +329,21 @@ void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStre
 void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a_in, unsigned char* rgb,
             double* canvas) {
   RenderArgs a = a_in;
-  const size_t per_form = sizeof(DevTriF) + 12; /* a form, its numerator, its triangle's number and list position */
-  const size_t list_bytes = (size_t)a.list_lds * per_form;
+  const size_t per_form = RT_LIST_LDS_BYTES, per_sform = RT_SLIST_LDS_BYTES;
+  const size_t list_bytes = (size_t)a.list_lds * per_form + (size_t)a.slist_lds * per_sform;
+  /* what fits behind `used` bytes of a workgroup's LDS budget `cap`: the camera rays' list first, then the shadow rays' */
+  auto fit_lists = [&](size_t used, size_t cap) {
+    a.list_lds = std::min(a.list_lds, (int)((cap - used) / per_form / 4 * 4));
+    used += (size_t)a.list_lds * per_form;
+    a.slist_lds = std::min(a.slist_lds, (int)((cap - used) / per_sform / 4 * 4));
+    return used + (size_t)a.slist_lds * per_sform;
+  };
   /* The counting build exists once per family: what it counts (rays, tests) does not depend on where the
    * primitives are staged, on the kinds present or on whether any material reflects. */
   if (count) {
     if (bvh) {
-      a.list_lds = 0; /* built for both kinds of primitives: camera rays walk the tree */
+      a.list_lds = 0; /* no LDS in this build: the lists are read from memory */
+      a.slist_lds = 0;
       launch_one<true, true, true, 0, 0>(0, grid, s, a, rgb, canvas);
     } else {
       launch_one<true, false, true, 0, 0>(list_bytes, grid, s, a, rgb, canvas);
@@ -349,21 +368,21 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
       if (cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
         stage = 3;
         lds = nodes + stacks;
-        a.list_lds = std::min(a.list_lds, (int)((kMaxLdsPerWorkgroup - lds) / per_form / 4 * 4)); /* longer lists are read from memory */
-        lds += (size_t)a.list_lds * per_form;
+        lds = fit_lists(lds, kMaxLdsPerWorkgroup); /* longer lists are read from memory */
       } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3)) {
         /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
          * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
          * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
         stage = 4;
         lds = stacks;
-        a.list_lds = std::min(a.list_lds, (int)(((reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3) - lds) / per_form / 4 * 4));
-        lds += (size_t)a.list_lds * per_form;
+        lds = fit_lists(lds, reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3);
       }
     }
   }
-  if (bvh && stage == 0) a.list_lds = 0;
-  if (!cur->use_lds) a.list_lds = 0;
+  if ((bvh && stage == 0) || !cur->use_lds) {
+    a.list_lds = 0;
+    a.slist_lds = 0;
+  }
   const int kind = (!bvh && cur->scene.n_tris == 0) ? 1 : (cur->scene.n_spheres == 0 ? 2 : 0);
   if (reflect) launch_family<true>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
   else launch_family<false>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
@@ -693,6 +712,136 @@ void shadow_blockers(double x0, double y0, double x1, double y1, unsigned long l
   }
 }
 
+/* Which triangles can stand between the light and a point that a camera ray of a tile sees?  (A world without
+ * spheres, every corner in front of the camera; cam_lists: per tile, the triangles its camera rays can hit.)
+ * The points such a ray can see lie in S = the listed triangles clipped to the tile's pyramid of rays (two pixels of
+ * margin, as in the rasterisation); is_shadowed (RayTracer.c:1410) sends its ray from a point EPSILON off the surface
+ * (:1371) to the light L and accepts hits on that stretch only, so everything it can meet lies within `pad` of the
+ * convex hull of S and L.  That hull is bounded from L's point of view: with m the coordinate axis along which S
+ * lies farthest from L, every point x of the hull other than L has (x - L)_m of the sign of S's, at most S's largest,
+ * and its central projection from L onto the plane (x - L)_m = +-1 falls into the rectangle that holds the
+ * projections of S (padded).  A triangle wholly on that side of L projects to the triangle of its corners'
+ * projections, so it can only meet the hull if the rectangle of those meets S's and its nearest corner is not beyond
+ * S; a triangle wholly on the other side cannot; one with corners on both sides is kept.  The lists are made per
+ * block of kListShadowBlock x kListShadowBlock tiles.  ok[tile] == 0: nothing known for this tile (S reaches around
+ * the light): its shadow rays test everything. */
+constexpr int kListShadowBlock = 2;
+void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const std::vector<int>& y_hi,
+                       const std::vector<std::vector<int32_t>>& cam_lists, double pad, std::vector<std::vector<int32_t>>& out,
+                       std::vector<unsigned char>& ok) {
+  const rt_camera& cam = cur->host_camera;
+  const double* iv = cam.inv_view;
+  const size_t nt = cur->mesh_world.size() / 9;
+  out.assign((size_t)tiles_x * tiles_y, std::vector<int32_t>());
+  ok.assign((size_t)tiles_x * tiles_y, 0);
+  const V3 O = {iv[3], iv[7], iv[11]}, L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
+  auto vert = [&](size_t k, int v) { const double* q = &cur->mesh_world[9 * k + 3 * v]; return V3{q[0], q[1], q[2]}; };
+  /* every triangle as L sees it along each axis: 0 = wholly on the + side, 1 = wholly on the - side, 2 = neither */
+  struct Chart { double a0, a1, b0, b1, near; int state; };
+  std::vector<Chart> chart(3 * nt);
+  for (size_t k = 0; k < nt; ++k)
+    for (int m = 0; m < 3; ++m) {
+      Chart c = {1e300, -1e300, 1e300, -1e300, 1e300, 0};
+      int pos = 0, neg = 0;
+      for (int v = 0; v < 3; ++v) {
+        const V3 p = vert(k, v);
+        const double q[3] = {p.x - L.x, p.y - L.y, p.z - L.z};
+        const double qm = q[m];
+        if (qm > pad) pos++;
+        else if (qm < -pad) neg++;
+        else continue;
+        const double am = std::fabs(qm), a = q[(m + 1) % 3] / am, b = q[(m + 2) % 3] / am;
+        c.a0 = std::fmin(c.a0, a); c.a1 = std::fmax(c.a1, a);
+        c.b0 = std::fmin(c.b0, b); c.b1 = std::fmax(c.b1, b);
+        c.near = std::fmin(c.near, am);
+      }
+      c.state = pos == 3 ? 0 : (neg == 3 ? 1 : 2);
+      if (!(c.a0 <= c.a1 && c.b0 <= c.b1)) c.state = 2; /* NaN */
+      chart[3 * k + m] = c;
+    }
+  std::vector<V3> pts;
+  for (int by = 0; by < tiles_y; by += kListShadowBlock)
+    for (int bx = 0; bx < tiles_x; bx += kListShadowBlock) {
+      pts.clear();
+      for (int ty = by; ty < std::min(tiles_y, by + kListShadowBlock); ++ty)
+        for (int tx = bx; tx < std::min(tiles_x, bx + kListShadowBlock); ++tx) {
+          const std::vector<int32_t>& seen = cam_lists[(size_t)ty * tiles_x + tx];
+          if (seen.empty()) continue;
+          /* the tile's pyramid of rays: the directions through the corners of its (padded) pixel rectangle */
+          const double x0 = tx * (double)RT_TILE_W - 2.0, x1 = (tx + 1) * (double)RT_TILE_W + 2.0;
+          const double y0 = (double)y_lo[ty] - 2.0, y1 = (double)y_hi[ty] + 3.0;
+          const double cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
+          V3 d[4], dc = {0, 0, 0}, side[4];
+          for (int c = 0; c < 4; ++c) {
+            const double wx = cam.half_width - cx[c] * cam.pixel_size, wy = cam.half_height - cy[c] * cam.pixel_size;
+            d[c] = {iv[0] * wx + iv[1] * wy - iv[2], iv[4] * wx + iv[5] * wy - iv[6], iv[8] * wx + iv[9] * wy - iv[10]};
+            dc = dc + d[c];
+          }
+          for (int c = 0; c < 4; ++c) {
+            side[c] = cross(d[c], d[(c + 1) % 4]);
+            if (dot(side[c], dc) < 0) side[c] = side[c] * -1.0;
+          }
+          for (int32_t j : seen) {
+            V3 poly[16], tmp[16];
+            int np = 3;
+            for (int v = 0; v < 3; ++v) poly[v] = vert((size_t)j, v);
+            for (int c = 0; c < 4 && np > 0; ++c) {
+              int nq = 0;
+              for (int i = 0; i < np; ++i) {
+                const V3 a = poly[i], b = poly[(i + 1) % np];
+                const double da = dot(side[c], a - O), db = dot(side[c], b - O);
+                if (da >= 0) tmp[nq++] = a;
+                if ((da >= 0) != (db >= 0)) tmp[nq++] = a + (b - a) * (da / (da - db));
+              }
+              np = nq;
+              for (int i = 0; i < np; ++i) poly[i] = tmp[i];
+            }
+            for (int i = 0; i < np; ++i) pts.push_back(poly[i]);
+          }
+        }
+      bool known = true;
+      std::vector<int32_t> blockers;
+      if (!pts.empty()) {
+        V3 sum = {0, 0, 0};
+        for (const V3& p : pts) sum = sum + (p - L);
+        const double sa[3] = {sum.x, sum.y, sum.z};
+        int m = 0;
+        for (int c = 1; c < 3; ++c) if (std::fabs(sa[c]) > std::fabs(sa[m])) m = c;
+        const double sg = sa[m] < 0 ? -1.0 : 1.0;
+        double a0 = 1e300, a1 = -1e300, b0 = 1e300, b1 = -1e300, far = 0.0;
+        for (const V3& p : pts) {
+          const double q[3] = {p.x - L.x, p.y - L.y, p.z - L.z};
+          const double qm = sg * q[m];
+          if (!(qm > 4.0 * pad)) { known = false; break; }
+          far = std::fmax(far, qm + pad);
+          for (int e = 0; e < 4; ++e) { /* the point moved by up to pad along every axis */
+            const double dq = (e & 1) ? pad : -pad, dm = (e & 2) ? pad : -pad;
+            const double a = (q[(m + 1) % 3] + dq) / (qm + dm), b = (q[(m + 2) % 3] + dq) / (qm + dm);
+            a0 = std::fmin(a0, a); a1 = std::fmax(a1, a);
+            b0 = std::fmin(b0, b); b1 = std::fmax(b1, b);
+          }
+        }
+        if (known) {
+          const double ea = 1e-9 * (1.0 + std::fmax(std::fabs(a0), std::fabs(a1))), eb = 1e-9 * (1.0 + std::fmax(std::fabs(b0), std::fabs(b1)));
+          a0 -= ea; a1 += ea; b0 -= eb; b1 += eb;
+          if (!(a0 <= a1 && b0 <= b1)) known = false;
+          for (size_t k = 0; k < nt && known; ++k) {
+            const Chart& c = chart[3 * k + (size_t)m];
+            if (c.state == 2) { blockers.push_back((int32_t)k); continue; }
+            if ((c.state == 0) != (sg > 0)) continue;
+            if (c.a1 >= a0 && c.a0 <= a1 && c.b1 >= b0 && c.b0 <= b1 && c.near <= far) blockers.push_back((int32_t)k);
+          }
+        }
+      }
+      for (int ty = by; ty < std::min(tiles_y, by + kListShadowBlock); ++ty)
+        for (int tx = bx; tx < std::min(tiles_x, bx + kListShadowBlock); ++tx) {
+          const size_t tile = (size_t)ty * tiles_x + tx;
+          ok[tile] = known ? 1 : 0;
+          if (known && !cam_lists[tile].empty()) out[tile] = blockers;
+        }
+    }
+}
+
 /* Behind the `entries` entries of `list`: four 64-bit words per entry, as for the masks, of which the first says where
  * the tile's triangles start in the arrays that follow (low half) and how many they are (high half; all ones: the
  * tile has more than max_per_tile and gets no list); then, from a 64-byte boundary on, copies of those triangles'
@@ -701,7 +850,7 @@ void shadow_blockers(double x0, double y0, double x1, double y1, unsigned long l
  * the numerator of a camera ray's t (host_tri_k); then their positions in the world's object list.
  * false: nothing appended (no triangles at all, or more than kMaxListEntries forms). */
 bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vector<std::vector<int32_t>>& tile_tris, int max_per_tile,
-                       Context::TilePlan* plan) {
+                       Context::TilePlan* plan, int tiles_x) {
   std::vector<long long> start(tile_tris.size(), -1);
   size_t total = 0;
   for (int e = 0; e < entries; ++e) {
@@ -716,20 +865,48 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vecto
   plan->list_total = 0;
   plan->list_max = max_per_tile;
   plan->list_longest = 0;
+  plan->shadow_longest = 0;
   if (total == 0 || total > kMaxListEntries) return false;
   for (int e = 0; e < plan->heavy && e < entries; ++e) {
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
     if (start[tile] >= 0) plan->list_longest = std::max(plan->list_longest, (int)tile_tris[tile].size());
   }
+  /* the shadow rays' lists: one per block of tiles (the tiles of a block share it), behind the camera rays' */
+  const bool shadows = plan->tile_shadow.size() == tile_tris.size() && plan->tile_shadow_ok.size() == tile_tris.size() && tiles_x > 0;
+  const int bx_n = (tiles_x + kListShadowBlock - 1) / kListShadowBlock;
+  std::vector<long long> shadow_start_of_block;
+  std::vector<long long> shadow_start(tile_tris.size(), -1);
+  if (shadows) {
+    const int tiles_y = (int)(tile_tris.size() / (size_t)tiles_x);
+    shadow_start_of_block.assign((size_t)bx_n * ((tiles_y + kListShadowBlock - 1) / kListShadowBlock + 1), -1);
+    for (int e = 0; e < entries; ++e) {
+      const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+      if (shadow_start[tile] >= 0 || !plan->tile_shadow_ok[tile] || tile_tris[tile].empty()) continue;
+      const std::vector<int32_t>& sl = plan->tile_shadow[tile];
+      if (sl.size() > (size_t)plan->shadow_max || total + sl.size() > kMaxListEntries) continue;
+      const size_t blk = (size_t)((int)(tile / (size_t)tiles_x) / kListShadowBlock) * bx_n + (size_t)((int)(tile % (size_t)tiles_x) / kListShadowBlock);
+      if (shadow_start_of_block[blk] < 0) {
+        shadow_start_of_block[blk] = (long long)total;
+        total += sl.size();
+      }
+      shadow_start[tile] = shadow_start_of_block[blk];
+      if (e < plan->heavy) plan->shadow_longest = std::max(plan->shadow_longest, (int)sl.size());
+    }
+  }
   if (getenv("RT_HIP_VERBOSE")) {
-    int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0};
+    int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0}, with_shadow = 0;
+    size_t shadow_sum = 0;
     for (int e = 0; e < plan->heavy && e < entries; ++e) {
-      const int n = (int)tile_tris[(size_t)(list[e] & RT_TILE_MASK)].size();
+      const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+      const int n = (int)tile_tris[tile].size();
       longest_any = std::max(longest_any, n);
       n_over[n > 512 ? 4 : (n > 256 ? 3 : (n > 128 ? 2 : (n > 64 ? 1 : 0)))]++;
+      if (shadows && shadow_start[tile] >= 0) { with_shadow++; shadow_sum += plan->tile_shadow[tile].size(); }
     }
-    fprintf(stderr, "tile lists: %zu forms, longest list in use %d (of any mesh tile: %d), mesh entries with <=64/128/256/512/more: %d %d %d %d %d\n",
-            total, plan->list_longest, longest_any, n_over[0], n_over[1], n_over[2], n_over[3], n_over[4]);
+    fprintf(stderr, "tile lists: %zu forms, longest list in use %d (of any mesh tile: %d), mesh entries with <=64/128/256/512/more: %d %d %d %d %d; "
+                    "shadow lists for %d mesh entries, mean %.1f, longest %d\n",
+            total, plan->list_longest, longest_any, n_over[0], n_over[1], n_over[2], n_over[3], n_over[4], with_shadow,
+            with_shadow ? (double)shadow_sum / with_shadow : 0.0, plan->shadow_longest);
   }
   list.resize((size_t)entries);
   if (list.size() % 2) list.push_back(0);
@@ -739,21 +916,32 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vecto
     const bool has = start[tile] >= 0;
     list.push_back(has ? (int32_t)(uint32_t)start[tile] : 0);
     list.push_back(has ? (int32_t)tile_tris[tile].size() : -1);
-    for (int k = 0; k < 6; ++k) list.push_back(0);
+    const bool hs = shadows && shadow_start[tile] >= 0;
+    list.push_back(hs ? (int32_t)(uint32_t)shadow_start[tile] : 0);
+    list.push_back(hs ? (int32_t)plan->tile_shadow[tile].size() : -1);
+    for (int k = 0; k < 4; ++k) list.push_back(0);
   }
   while (list.size() % 16) list.push_back(0);
   plan->list_forms = list.size();
   plan->list_total = total;
   const size_t words = sizeof(DevTriF) / 4;
   list.resize(plan->list_forms + total * words + 3 * total, 0);
+  auto put = [&](size_t at, int32_t tri, bool camera) {
+    memcpy(&list[plan->list_forms + at * words], &cur->host_trif[(size_t)tri], sizeof(DevTriF));
+    list[plan->list_forms + total * words + at] = tri;
+    if (camera) {
+      memcpy(&list[plan->list_forms + total * words + total + at], &cur->host_tri_k[(size_t)tri], sizeof(float));
+      list[plan->list_forms + total * words + 2 * total + at] = cur->host_tri_order[(size_t)tri];
+    }
+  };
   for (size_t tile = 0; tile < tile_tris.size(); ++tile) {
-    if (start[tile] < 0) continue;
-    const std::vector<int32_t>& l = tile_tris[tile];
-    for (size_t k = 0; k < l.size(); ++k) {
-      memcpy(&list[plan->list_forms + ((size_t)start[tile] + k) * words], &cur->host_trif[(size_t)l[k]], sizeof(DevTriF));
-      list[plan->list_forms + total * words + (size_t)start[tile] + k] = l[k];
-      memcpy(&list[plan->list_forms + total * words + total + (size_t)start[tile] + k], &cur->host_tri_k[(size_t)l[k]], sizeof(float));
-      list[plan->list_forms + total * words + 2 * total + (size_t)start[tile] + k] = cur->host_tri_order[(size_t)l[k]];
+    if (start[tile] >= 0) {
+      const std::vector<int32_t>& l = tile_tris[tile];
+      for (size_t k = 0; k < l.size(); ++k) put((size_t)start[tile] + k, l[k], true);
+    }
+    if (shadows && shadow_start[tile] >= 0) { /* the tiles of a block write the same entries */
+      const std::vector<int32_t>& l = plan->tile_shadow[tile];
+      for (size_t k = 0; k < l.size(); ++k) put((size_t)shadow_start[tile] + k, l[k], false);
     }
   }
   return true;
@@ -873,6 +1061,7 @@ int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStre
   a.list_forms = 0;
   a.list_total = 0;
   a.list_lds = 0;
+  a.slist_lds = 0;
   n_blocks = plan_blocks(plan);
   return RT_OK;
 }
@@ -893,6 +1082,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.list_forms = 0;
   a.list_total = 0;
   a.list_lds = 0;
+  a.slist_lds = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
   if (masked_world(bvh) && cur->light_per_block > 1) {
@@ -1060,7 +1250,16 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     if (have_cover && want_lists) {
       entries_only = heavy;
       const bool few_tiles = (size_t)plan->heavy <= (size_t)(cur->split_max_per_cu + 2) * cur->n_cu && !overlap;
-      if (!append_tile_lists(heavy, plan->entries, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan))
+      plan->tile_shadow.clear();
+      plan->tile_shadow_ok.clear();
+      plan->shadow_max = bvh ? cur->shadow_list_max_walk : 0x7fffffff;
+      if (cur->shadow_lists && plan->shadow_max > 0 && cur->mesh_world.size() == 9 * (size_t)cur->scene.n_tris) {
+        double reach = 1.0;
+        for (double v : cur->mesh_world) reach = std::fmax(reach, std::fabs(v));
+        for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
+        shadow_tile_lists(tiles_x, tiles_y, y_lo, y_hi, tri_lists, 8.0 * RT_EPSILON + 1e-9 * reach, plan->tile_shadow, plan->tile_shadow_ok);
+      }
+      if (!append_tile_lists(heavy, plan->entries, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan, tiles_x))
         want_lists = false;
     }
     if (have_cover && want_lists) {
@@ -1107,7 +1306,11 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     if (src != RT_OK) return src;
     if (plan->refine_left > 0) plan->host_list = entries_only.empty() ? heavy : entries_only;
     else plan->host_list.clear();
-    if (plan->refine_left <= 0 || !plan->list_forms) { plan->tile_tris.clear(); plan->tile_tris.shrink_to_fit(); }
+    if (plan->refine_left <= 0 || !plan->list_forms) {
+      plan->tile_tris.clear(); plan->tile_tris.shrink_to_fit();
+      plan->tile_shadow.clear(); plan->tile_shadow.shrink_to_fit();
+      plan->tile_shadow_ok.clear();
+    }
   }
   cur->launch_plan = plan;
   cur->launch_tile_list = plan->d_list;
@@ -1119,6 +1322,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.list_forms = (int32_t)plan->list_forms;
   a.list_total = (int32_t)plan->list_total;
   a.list_lds = plan->list_forms && cur->list_lds ? (std::min(plan->list_longest, kMaxLdsListForms) + 3) / 4 * 4 : 0;
+  a.slist_lds = plan->list_forms && cur->list_lds ? (std::min(plan->shadow_longest, kMaxLdsShadowForms) + 3) / 4 * 4 : 0;
   n_blocks = plan_blocks(plan);
   return RT_OK;
 }
@@ -1430,7 +1634,7 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     std::vector<int32_t> full;
     if (with_lists) { /* the entries changed: so do the words behind them that say where each entry's triangle list lies */
       full = l;
-      if (!append_tile_lists(full, (int)l.size(), plan->tile_tris, plan->list_max, plan)) return (int)RT_ERR_INVALID;
+      if (!append_tile_lists(full, (int)l.size(), plan->tile_tris, plan->list_max, plan, (cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W)) return (int)RT_ERR_INVALID;
     }
     const int src = store_plan(plan, key, with_lists ? full : l, s);
     if (src != RT_OK) return src;
@@ -1441,6 +1645,8 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     a.list_forms = (int32_t)plan->list_forms;
     a.list_total = (int32_t)plan->list_total;
     a.list_lds = plan->list_forms && cur->list_lds ? (std::min(plan->list_longest, kMaxLdsListForms) + 3) / 4 * 4 : 0;
+    a.slist_lds = plan->list_forms && cur->list_lds ? (std::min(plan->shadow_longest, kMaxLdsShadowForms) + 3) / 4 * 4 : 0;
+  a.slist_lds = plan->list_forms && cur->list_lds ? (std::min(plan->shadow_longest, kMaxLdsShadowForms) + 3) / 4 * 4 : 0;
     a.n_heavy = plan->heavy;
     a.n_entries = plan->entries;
     n_blocks = plan_blocks(plan);
@@ -1524,6 +1730,9 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
   plan->tile_tris.clear();
   plan->tile_tris.shrink_to_fit();
+  plan->tile_shadow.clear();
+  plan->tile_shadow.shrink_to_fit();
+  plan->tile_shadow_ok.clear();
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return rc;
@@ -1565,6 +1774,8 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
       a.list_forms = 0;
       a.list_total = 0;
       a.list_lds = 0;
+      a.slist_lds = 0;
+  a.slist_lds = 0;
       n_blocks = (int)n_tiles;
       bvh = false;
       const int prc = plan_general_tiles(p, rows, s, a);
@@ -1899,6 +2110,8 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_TILE_LISTS")) cur->tile_lists = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_LIST_MAX_WALK")) cur->list_max_walk = cur->list_max_walk_few = atoi(e);
   if (const char* e = getenv("RT_HIP_LIST_LDS")) cur->list_lds = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_SHADOW_LISTS")) cur->shadow_lists = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_SHADOW_LIST_MAX_WALK")) cur->shadow_list_max_walk = atoi(e);
   if (const char* e = getenv("RT_HIP_SHADOW_MASKS")) cur->shadow_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SPHERE_MASKS")) cur->sphere_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */
@@ -2124,11 +2337,19 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   cur->host_trif.clear();
   cur->host_tri_k.clear();
   cur->host_tri_order.clear();
+  cur->mesh_world.clear();
   if (ns == 0 && nt > 0 && nt <= kMaxListTris) {
     cur->host_trif.assign(htf.begin(), htf.begin() + nt);
     cur->host_tri_k.resize((size_t)nt);
     cur->host_tri_order.resize((size_t)nt);
     for (int k = 0; k < nt; ++k) cur->host_tri_order[k] = ht[k].order;
+    cur->mesh_world.resize(9 * (size_t)nt);
+    for (int k = 0; k < nt; ++k)
+      for (int c = 0; c < 3; ++c) {
+        cur->mesh_world[9 * (size_t)k + c] = ht[k].p1[c];
+        cur->mesh_world[9 * (size_t)k + 3 + c] = ht[k].p1[c] + ht[k].e1[c];
+        cur->mesh_world[9 * (size_t)k + 6 + c] = ht[k].p1[c] + ht[k].e2[c];
+      }
     for (int k = 0; k < nt; ++k) {
       const double* p1 = ht[k].p1;
       const double* e1 = ht[k].e1;
@@ -2448,6 +2669,7 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   cur->host_trif.clear();
   cur->host_tri_k.clear();
   cur->host_tri_order.clear();
+  cur->mesh_world.clear();
   cur->tri_depth.clear();
   HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
   cur->scene_serial++;

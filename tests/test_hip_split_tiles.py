@@ -1,7 +1,8 @@
 """Crowded mesh tiles run as two or four workgroups with a half or a quarter of each wave's lanes: whatever the
 split, every pixel is traced exactly once and the image equals the exhaustive loop's and the oracle's.  The same
 holds with and without the per-tile triangle lists that camera rays run down instead of walking the tree (none,
-for every tile, only for tiles with at most 8 triangles)."""
+for every tile, only for tiles with at most 8 triangles), and of the lists of possible blockers that the shadow rays
+run down."""
 import json
 import os
 import subprocess
@@ -17,7 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("parts,tiles,min_cost,lists", [(2, 100000, 1, {}), (4, 100000, 1, {}), (4, 7, 1, {}), (1, 0, 1, {}),
                                                         (2, 100000, 1, {"RT_HIP_TILE_LISTS": "0"}),
                                                         (4, 100000, 1, {"RT_HIP_LIST_MAX_WALK": "8"}),
-                                                        (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "100000"})])
+                                                        (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "100000"}),
+                                                        (2, 100000, 1, {"RT_HIP_SHADOW_LISTS": "0"}),
+                                                        (4, 100000, 1, {"RT_HIP_SHADOW_LIST_MAX_WALK": "100000", "RT_HIP_LIST_MAX_WALK": "100000"}),
+                                                        (1, 0, 1, {"RT_HIP_SHADOW_LIST_MAX_WALK": "8", "RT_HIP_LIST_LDS": "0"})])
 def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost, lists):
     env = dict(os.environ, RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
     r = subprocess.run([sys.executable, os.path.join(HERE, "split_tiles_child.py")], env=env, capture_output=True, text=True,
