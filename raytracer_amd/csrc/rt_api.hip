@@ -56,7 +56,10 @@ struct Context {
   /* Frames that walk the tree: shadow rays of a tile with at most this many such triangles would run down the list
    * instead.  Off: the tiles whose waves a frame waits for have the longest lists (lighthouse 1080p: up to 790 possible
    * blockers for a block of the lantern room, 140 on average), and those walk in any case; with lists of up to 64 ..
-   * 192 the 1080p frames stay within 1 % and 4K gains 5 %, with lists of up to 320 they take 75 % longer. */
+   * 192 the 1080p frames stay within 1 % and 4K gains 5 %, with lists of up to 320 they take 75 % longer (a walk
+   * leaves out what lies behind the ray's start or beyond the light box by box; in a list every triangle whose plane
+   * the ray's line crosses inside its outline costs the double-precision routine).  Lists per single tile are no
+   * shorter where it matters (longest 686). */
   int shadow_list_max_walk = 0;
   bool list_lds = true;     /* a mesh tile's workgroup copies its list to LDS (false: read through scalar loads) */
   /* Launches that walk a tree: the camera rays of a tile with at most this many triangles in its list run down the list
@@ -65,7 +68,7 @@ struct Context {
    * as long as its slowest wave, which sits in the most crowded tile: there a long list takes as long as the walk
    * (about 300 cycles per triangle of the list against 70 node steps and 16 leaves), so only the short ones are used
    * (1080p lighthouse 57.5 us with no lists, 52 with lists of up to 64, 55.7 up to 128, 58 up to 256). */
-  int list_max_walk = 256, list_max_walk_few = 64;
+  int list_max_walk = 256, list_max_walk_few = 256;
   bool cover_tiles = true;  /* find the mesh tiles by rasterising the triangles (false: by the rectangle of the mesh's bounds) */
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
@@ -136,6 +139,7 @@ struct Context {
   const int32_t* launch_tile_list = nullptr; /* argument of the launch being issued */
   const unsigned long long* launch_tile_mask = nullptr; /* likewise: per-entry pairs of triangle masks, or nullptr */
   TilePlan* launch_plan = nullptr;           /* the plan it came from (plan_tiles), nullptr for an unplanned launch */
+  size_t launch_lds = 0;                     /* dynamic LDS per workgroup of the last launch() */
   unsigned long long* launch_counters = nullptr; /* counters argument of the launch being issued (nullptr: d_counters) */
   void* d_tri_primary = nullptr;
   void* d_sph_primary = nullptr;
@@ -384,6 +388,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
     a.slist_lds = 0;
   }
   const int kind = (!bvh && cur->scene.n_tris == 0) ? 1 : (cur->scene.n_spheres == 0 ? 2 : 0);
+  cur->launch_lds = lds;
   if (reflect) launch_family<true>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
   else launch_family<false>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
 }
@@ -1613,7 +1618,7 @@ int check_params(const rt_render_params* p) {
  * alone walks nearly the same path in every lane of a tile and only pays for the extra workgroups). */
 int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s, RenderArgs& a, unsigned char* d_rgb,
                  double* d_canvas, int& n_blocks) {
-  const int slots = cur->n_cu * 4 * (reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN);
+  int slots = cur->n_cu * 4 * (reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN);
   const int rounds = plan->refine_left;
   plan->refine_left = 0;
   const int n_light = plan->entries - plan->heavy;
@@ -1692,6 +1697,13 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
       for (int w = 0; w < 4; ++w) { m = std::max(m, cyc[(size_t)i * 4 + w]); total += cyc[(size_t)i * 4 + w]; }
       cost[i] = m;
       slowest = std::max(slowest, m);
+    }
+    /* wave slots of the chip for this kernel: a workgroup is one wave per SIMD, and the LDS it asks for may allow
+     * fewer workgroups per CU than the registers do */
+    {
+      const int by_regs = reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN;
+      const int by_lds = cur->launch_lds ? (int)((size_t)160 * 1024 / cur->launch_lds) : by_regs;
+      slots = cur->n_cu * 4 * std::max(1, std::min(by_regs, by_lds));
     }
     const double even = (double)total / slots; /* cycles of a launch whose waves fill every slot to the end */
     if (getenv("RT_HIP_VERBOSE")) {
