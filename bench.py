@@ -89,10 +89,12 @@ def pmc_traffic():
 def executed_flops(st, n_spheres, brute):
     """(single-precision FLOPs, double-precision FLOPs) of the work one launch really did, from the counting
     build's counters.  Exhaustive kernels run the single-precision test on every triangle and confirm the
-    survivors in double precision; the BVH walk tests a leaf's triangles in double precision directly."""
+    survivors in double precision; the BVH walk tests a leaf's triangles in double precision directly, and its
+    camera rays run the single-precision test down their tile's list (of those, the tests that were not followed by
+    a double-precision one are counted: a lower bound)."""
     tri_tests = st.prim_tests - st.sphere_tests
     sph_primary = min(st.sphere_tests, st.rays_primary * n_spheres)
-    f32 = ((tri_tests * FLOP_TRI_FILTER if brute else 0) + sph_primary * FLOP_SPHERE_FILTER_PRIMARY
+    f32 = ((tri_tests if brute else max(0, tri_tests - st.tri_exact)) * FLOP_TRI_FILTER + sph_primary * FLOP_SPHERE_FILTER_PRIMARY
            + (st.sphere_tests - sph_primary) * FLOP_SPHERE_FILTER + st.node_tests * FLOP_PER_BOX_TEST)
     f64 = (st.tri_exact * FLOP_TRI_EXACT + st.sphere_exact * FLOP_SPHERE_EXACT + st.rays_primary * FLOP_PER_PRIMARY_RAY
            + st.rays_shadow * FLOP_PER_SHADED_HIT)
