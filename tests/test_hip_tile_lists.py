@@ -119,3 +119,20 @@ def test_counting_build_still_sees_every_entry_of_a_listed_camera_ray(hip):
     ref, _ = hip.render(accel=REFERENCE)
     want, _ = O.render_rgb(s)
     assert np.array_equal(ref, want)
+
+
+@pytest.mark.parametrize("level,w,h,reflective", [(3, 203, 131, 0.0), (4, 171, 99, 0.25), (5, 160, 120, 0.0)])
+def test_tessellated_spheres_with_many_small_triangles_per_tile(hip, level, w, h, reflective):
+    """1280, 5120 and 20,480 triangles on a sphere: tiles with hundreds of small triangles in their lists (front and
+    back of the sphere), lists longer than what a workgroup keeps in LDS, shadow rays that graze the silhouette."""
+    from test_hip_parity import icosphere, mesh_scene
+
+    s = mesh_scene(icosphere(level), w, h, reflective=reflective)
+    hip.upload(s)
+    want, ost = O.render_rgb(s)
+    walked, wst = hip.render(accel=BVH, count_rays=True)
+    assert np.array_equal(walked, want) and wst.rays == ost.rays
+    if level < 5:  # the exhaustive loop over 20,480 triangles is left to the smaller meshes
+        got, st = hip.render(accel=BRUTE, count_rays=True)
+        assert np.array_equal(got, want) and st.rays == ost.rays
+        assert st.prim_tests < st.rays * s.n_tris // 2
