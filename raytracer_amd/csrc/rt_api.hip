@@ -287,7 +287,8 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
 
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
-constexpr int kMaxLdsTris = 512;      /* 512 * 64 B = 32 KiB of single-precision forms: four workgroups still fit a CU */
+constexpr int kMaxLdsTris = 320;      /* 320 * 64 B = 20 KiB of single-precision forms beside the 18 KiB the kernel keeps for values
+                                         that wait out its loops: four workgroups still fit a CU */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
 constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
 constexpr int kShadowBlock = 4;            /* shadow masks are worked out per block of this many tiles squared */
@@ -360,7 +361,8 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
     if (!bvh && a.list_forms) {
       stage = 0; /* camera rays read their tile's list (from the workgroup's copy in LDS if it fits), the others the whole
                     array through scalar loads */
-      lds = list_bytes;
+      /* three workgroups per CU (the large-mesh kernel runs three waves per SIMD) beside the kernel's own 18 KiB */
+      lds = fit_lists(RT_PARK_BYTES, (size_t)160 * 1024 / 3) - RT_PARK_BYTES;
     } else if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
       stage = 1;
       lds = (size_t)cur->scene.n_tris * sizeof(DevTriF);
