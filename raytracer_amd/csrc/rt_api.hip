@@ -53,14 +53,13 @@ struct Context {
   bool tile_masks = true;   /* meshes of up to 64 triangles: camera rays test only the triangles that cover their tile */
   bool tile_lists = true;   /* larger meshes walked exhaustively: per-tile lists of those triangles instead of masks */
   bool shadow_lists = true; /* with the camera rays' lists: per block of tiles, the triangles that can lie between what those rays see and the light */
-  /* Frames that walk the tree: shadow rays of a tile with at most this many such triangles would run down the list
-   * instead.  Off: the tiles whose waves a frame waits for have the longest lists (lighthouse 1080p: up to 790 possible
-   * blockers for a block of the lantern room, 140 on average), and those walk in any case; with lists of up to 64 ..
-   * 192 the 1080p frames stay within 1 % and 4K gains 5 %, with lists of up to 320 they take 75 % longer (a walk
-   * leaves out what lies behind the ray's start or beyond the light box by box; in a list every triangle whose plane
-   * the ray's line crosses inside its outline costs the double-precision routine).  Lists per single tile are no
-   * shorter where it matters (longest 686). */
-  int shadow_list_max_walk = 0;
+  /* Only the exhaustive loop uses these lists.  Frames that walk the tree were measured with them as well: the tiles
+   * whose waves a frame waits for have the longest lists (lighthouse 1080p: up to 790 possible blockers for a block of
+   * the lantern room, 140 on average); with lists of up to 64 .. 192 the 1080p frames stayed within 1 % and 4K gained
+   * 5 %, with lists of up to 320 they took 75 % longer (a walk leaves out what lies behind the ray's start or beyond
+   * the light box by box; in a list every triangle whose plane the ray's line crosses inside its outline costs the
+   * double-precision routine), and the support for it cost the walking kernels 70 spilled scalar registers.  Lists per
+   * single tile are no shorter where it matters (longest 686). */
   bool list_lds = true;     /* a mesh tile's workgroup copies its list to LDS (false: read through scalar loads) */
   /* Launches that walk a tree: the camera rays of a tile with at most this many triangles in its list run down the list
    * instead (0: never).  A launch of many mesh tiles is bound by throughput, and the list costs less work than the walk
@@ -334,6 +333,7 @@ void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStre
 void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a_in, unsigned char* rgb,
             double* canvas) {
   RenderArgs a = a_in;
+  if (bvh) a.slist_lds = 0;
   const size_t per_form = RT_LIST_LDS_BYTES, per_sform = RT_SLIST_LDS_BYTES;
   const size_t list_bytes = (size_t)a.list_lds * per_form + (size_t)a.slist_lds * per_sform;
   /* what fits behind `used` bytes of a workgroup's LDS budget `cap`: the camera rays' list first, then the shadow rays' */
@@ -1259,7 +1259,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       const bool few_tiles = (size_t)plan->heavy <= (size_t)(cur->split_max_per_cu + 2) * cur->n_cu && !overlap;
       plan->tile_shadow.clear();
       plan->tile_shadow_ok.clear();
-      plan->shadow_max = bvh ? cur->shadow_list_max_walk : 0x7fffffff;
+      plan->shadow_max = bvh ? 0 : 0x7fffffff;
       if (cur->shadow_lists && plan->shadow_max > 0 && cur->mesh_world.size() == 9 * (size_t)cur->scene.n_tris) {
         double reach = 1.0;
         for (double v : cur->mesh_world) reach = std::fmax(reach, std::fabs(v));
@@ -2125,7 +2125,6 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_LIST_MAX_WALK")) cur->list_max_walk = cur->list_max_walk_few = atoi(e);
   if (const char* e = getenv("RT_HIP_LIST_LDS")) cur->list_lds = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SHADOW_LISTS")) cur->shadow_lists = atoi(e) != 0;
-  if (const char* e = getenv("RT_HIP_SHADOW_LIST_MAX_WALK")) cur->shadow_list_max_walk = atoi(e);
   if (const char* e = getenv("RT_HIP_SHADOW_MASKS")) cur->shadow_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_SPHERE_MASKS")) cur->sphere_masks = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_TILE_PLAN")) cur->tile_plan = atoi(e) != 0; /* 0 = row-major tiles */

@@ -20,8 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                         (4, 100000, 1, {"RT_HIP_LIST_MAX_WALK": "8"}),
                                                         (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "100000"}),
                                                         (2, 100000, 1, {"RT_HIP_SHADOW_LISTS": "0"}),
-                                                        (4, 100000, 1, {"RT_HIP_SHADOW_LIST_MAX_WALK": "100000", "RT_HIP_LIST_MAX_WALK": "100000"}),
-                                                        (1, 0, 1, {"RT_HIP_SHADOW_LIST_MAX_WALK": "8", "RT_HIP_LIST_LDS": "0"})])
+                                                        (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "24", "RT_HIP_LIST_LDS": "0"})])
 def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost, lists):
     env = dict(os.environ, RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
     r = subprocess.run([sys.executable, os.path.join(HERE, "split_tiles_child.py")], env=env, capture_output=True, text=True,
