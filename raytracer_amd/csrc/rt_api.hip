@@ -856,8 +856,8 @@ void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, c
  * copy), so that a tile's camera rays read consecutive memory; then the numbers of the same triangles; then, for each,
  * the numerator of a camera ray's t (host_tri_k); then their positions in the world's object list.
  * false: nothing appended (no triangles at all, or more than kMaxListEntries forms). */
-bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vector<std::vector<int32_t>>& tile_tris, int max_per_tile,
-                       Context::TilePlan* plan, int tiles_x) {
+bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const std::vector<std::vector<int32_t>>& tile_tris,
+                       int max_per_tile, Context::TilePlan* plan, int tiles_x) {
   std::vector<long long> start(tile_tris.size(), -1);
   size_t total = 0;
   for (int e = 0; e < entries; ++e) {
@@ -874,7 +874,7 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vecto
   plan->list_longest = 0;
   plan->shadow_longest = 0;
   if (total == 0 || total > kMaxListEntries) return false;
-  for (int e = 0; e < plan->heavy && e < entries; ++e) {
+  for (int e = 0; e < heavy && e < entries; ++e) {
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
     if (start[tile] >= 0) plan->list_longest = std::max(plan->list_longest, (int)tile_tris[tile].size());
   }
@@ -897,13 +897,13 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, const std::vecto
         total += sl.size();
       }
       shadow_start[tile] = shadow_start_of_block[blk];
-      if (e < plan->heavy) plan->shadow_longest = std::max(plan->shadow_longest, (int)sl.size());
+      if (e < heavy) plan->shadow_longest = std::max(plan->shadow_longest, (int)sl.size());
     }
   }
   if (getenv("RT_HIP_VERBOSE")) {
     int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0}, with_shadow = 0;
     size_t shadow_sum = 0;
-    for (int e = 0; e < plan->heavy && e < entries; ++e) {
+    for (int e = 0; e < heavy && e < entries; ++e) {
       const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
       const int n = (int)tile_tris[tile].size();
       longest_any = std::max(longest_any, n);
@@ -1266,7 +1266,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
         for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
         shadow_tile_lists(tiles_x, tiles_y, y_lo, y_hi, tri_lists, 8.0 * RT_EPSILON + 1e-9 * reach, plan->tile_shadow, plan->tile_shadow_ok);
       }
-      if (!append_tile_lists(heavy, plan->entries, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan, tiles_x))
+      if (!append_tile_lists(heavy, plan->entries, plan->heavy, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan, tiles_x))
         want_lists = false;
     }
     if (have_cover && want_lists) {
@@ -1641,7 +1641,8 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     std::vector<int32_t> full;
     if (with_lists) { /* the entries changed: so do the words behind them that say where each entry's triangle list lies */
       full = l;
-      if (!append_tile_lists(full, (int)l.size(), plan->tile_tris, plan->list_max, plan, (cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W)) return (int)RT_ERR_INVALID;
+      if (!append_tile_lists(full, (int)l.size(), (int)l.size() - n_light, plan->tile_tris, plan->list_max, plan, (cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W))
+        return (int)RT_ERR_INVALID;
     }
     const int src = store_plan(plan, key, with_lists ? full : l, s);
     if (src != RT_OK) return src;
