@@ -74,6 +74,7 @@ struct Context {
   bool lds_stack = true;
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
+  bool split_resort = true; /* after the refinement: the winning list once more, in the order of its own measurement */
   int split_refine = 3;    /* launches that measure their waves and split the slowest tiles further */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
@@ -1634,6 +1635,7 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   HIP_TRY(hipEventCreate(&e0));
   if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return RT_ERR_HIP; }
   float best_ms = 1e30f;
+  std::vector<unsigned> best_cost; /* the slowest wave of every mesh entry of best_list, as measured with that list */
   bool current_is_best = true;
   int rc = RT_OK;
   const bool with_lists = plan->list_forms != 0 && !plan->tile_tris.empty();
@@ -1685,13 +1687,6 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_probe);
     if (!hip_ok(e, "split refinement probe")) { rc = RT_ERR_HIP; break; }
-    if (ms < best_ms * (round == 0 ? 1.0f : 0.98f)) {
-      best_ms = ms;
-      best_list = list;
-      current_is_best = true;
-    } else {
-      current_is_best = false;
-    }
     std::vector<unsigned> cost((size_t)nh);
     unsigned long long total = 0;
     unsigned slowest = 0;
@@ -1700,6 +1695,14 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
       for (int w = 0; w < 4; ++w) { m = std::max(m, cyc[(size_t)i * 4 + w]); total += cyc[(size_t)i * 4 + w]; }
       cost[i] = m;
       slowest = std::max(slowest, m);
+    }
+    if (ms < best_ms * (round == 0 ? 1.0f : 0.98f)) {
+      best_ms = ms;
+      best_list = list;
+      best_cost = cost;
+      current_is_best = true;
+    } else {
+      current_is_best = false;
     }
     /* wave slots of the chip for this kernel: a workgroup is one wave per SIMD, and the LDS it asks for may allow
      * fewer workgroups per CU than the registers do */
@@ -1741,6 +1744,41 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     list.swap(next);
     rc = adopt(list);
     current_is_best = false;
+  }
+  /* The list that won was put in order by what the round before it had measured, with estimates for the entries it
+   * had just split.  Its own measurement is at hand: the same entries, longest first by that, are tried as well
+   * (an entry that was guessed too cheap starts in a later round of workgroups, and the frame then waits for it). */
+  if (rc == RT_OK && cur->split_resort && best_cost.size() + (size_t)n_light == best_list.size() && best_cost.size() > 1) {
+    const size_t nh = best_cost.size();
+    std::vector<int32_t> order(nh);
+    for (size_t i = 0; i < nh; ++i) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return best_cost[(size_t)x] > best_cost[(size_t)y]; });
+    std::vector<int32_t> resorted;
+    resorted.reserve(best_list.size());
+    for (int32_t i : order) resorted.push_back(best_list[(size_t)i]);
+    resorted.insert(resorted.end(), best_list.begin() + (long)nh, best_list.end());
+    if (resorted != best_list && (rc = adopt(resorted)) == RT_OK) {
+      float ms = 1e30f;
+      hipError_t e = hipSuccess;
+      for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) {
+        e = hipEventRecord(e0, s);
+        launch(false, bvh, reflect, dim3((unsigned)n_blocks), s, a, d_rgb, d_canvas);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float one = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&one, e0, e1);
+        if (rep > 0 && one < ms) ms = one;
+      }
+      if (!hip_ok(e, "split refinement (re-ordered list)")) rc = RT_ERR_HIP;
+      if (getenv("RT_HIP_VERBOSE")) fprintf(stderr, "refine_split re-ordered by its own measurement: %.1f us (best so far %.1f us)\n", ms * 1e3, best_ms * 1e3);
+      if (rc == RT_OK && ms < best_ms * 0.99f) {
+        best_list.swap(resorted);
+        current_is_best = true;
+      } else {
+        current_is_best = false;
+      }
+    }
   }
   if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
   plan->tile_tris.clear();
@@ -2113,6 +2151,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_PARTS")) cur->split_parts = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) cur->split_min_cost = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_REFINE")) cur->split_refine = atoi(e);
+  if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */
