@@ -74,6 +74,9 @@ struct Context {
   bool lds_stack = true;
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
+  bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
+  int part_shadow_max = 96; /* ... and lists for their shadow rays up to this length (0: none) */
+  int split_max_lg = 4;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave) */
   bool split_resort = true; /* after the refinement: the winning list once more, in the order of its own measurement */
   int split_refine = 3;    /* launches that measure their waves and split the slowest tiles further */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
@@ -126,6 +129,9 @@ struct Context {
     std::vector<std::vector<int32_t>> tile_shadow; /* by tile number: the triangles of its shadow rays' list (with tile_tris) */
     std::vector<unsigned char> tile_shadow_ok;     /* by tile number: 1 = tile_shadow holds every possible blocker, 0 = unknown */
     int shadow_max = 0, shadow_longest = 0;        /* as list_max / list_longest */
+    bool part_lists = false;       /* walks: a part of a tile split into four or more gets lists of its own rectangle */
+    int part_shadow_max = 0;       /* ... and a shadow rays' list if that has at most this many triangles */
+    int rows = 0, band_rows = 1, n_ranks = 1, rank = 0; /* the launch's packed rows and how they map to image rows */
     size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
                                       ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
@@ -334,7 +340,7 @@ void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStre
 void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const RenderArgs& a_in, unsigned char* rgb,
             double* canvas) {
   RenderArgs a = a_in;
-  if (bvh) a.slist_lds = 0;
+
   const size_t per_form = RT_LIST_LDS_BYTES, per_sform = RT_SLIST_LDS_BYTES;
   const size_t list_bytes = (size_t)a.list_lds * per_form + (size_t)a.slist_lds * per_sform;
   /* what fits behind `used` bytes of a workgroup's LDS budget `cap`: the camera rays' list first, then the shadow rays' */
@@ -544,6 +550,29 @@ bool covered_tiles(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const
 }
 
 
+/* The test of covered_tiles for any pixel rectangle [x0, x1) x [y0, y1) of the image: false only if no camera ray
+ * through it can reach triangle k (same margins). */
+bool tri_reaches_rect(size_t k, double x0, double x1, double y0, double y1) {
+  const double margin = 2.0;
+  const double* q = &cur->tri_xy[6 * k];
+  const double bx0 = std::fmin(q[0], std::fmin(q[2], q[4])) - margin, bx1 = std::fmax(q[0], std::fmax(q[2], q[4])) + margin;
+  const double by0 = std::fmin(q[1], std::fmin(q[3], q[5])) - margin, by1 = std::fmax(q[1], std::fmax(q[3], q[5])) + margin;
+  if (!(bx0 <= bx1 && by0 <= by1)) return true; /* NaN */
+  if (bx1 < x0 || bx0 > x1 || by1 < y0 || by0 > y1) return false;
+  const double area2 = (q[2] - q[0]) * (q[5] - q[1]) - (q[3] - q[1]) * (q[4] - q[0]);
+  const double extent = (bx1 - bx0) + (by1 - by0);
+  if (!(std::fabs(area2) > 1e-6 * extent * extent)) return true; /* a sliver: the rectangle only */
+  const double sg = area2 > 0 ? 1.0 : -1.0;
+  const double xlo = x0 - margin, xhi = x1 + margin, ylo = y0 - margin, yhi = y1 + margin;
+  for (int e = 0; e < 3; ++e) {
+    const double ax = q[2 * e], ay = q[2 * e + 1];
+    const double dx = sg * (q[2 * ((e + 1) % 3)] - ax), dy = sg * (q[2 * ((e + 1) % 3) + 1] - ay);
+    const double cx = dy < 0 ? xhi : xlo, cy = dx > 0 ? yhi : ylo;
+    if (dx * (cy - ay) - dy * (cx - ax) < 0.0) return false;
+  }
+  return true;
+}
+
 struct V3 {
   double x, y, z;
 };
@@ -734,26 +763,19 @@ void shadow_blockers(double x0, double y0, double x1, double y1, unsigned long l
  * block of kListShadowBlock x kListShadowBlock tiles.  ok[tile] == 0: nothing known for this tile (S reaches around
  * the light): its shadow rays test everything. */
 constexpr int kListShadowBlock = 2;
-void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const std::vector<int>& y_hi,
-                       const std::vector<std::vector<int32_t>>& cam_lists, double pad, std::vector<std::vector<int32_t>>& out,
-                       std::vector<unsigned char>& ok) {
-  const rt_camera& cam = cur->host_camera;
-  const double* iv = cam.inv_view;
+/* every triangle as the light L sees it along each axis: 0 = wholly on the + side, 1 = wholly on the - side, 2 = neither */
+struct LightChart { double a0, a1, b0, b1, near; int state; };
+void light_charts(double pad, std::vector<LightChart>& chart) {
   const size_t nt = cur->mesh_world.size() / 9;
-  out.assign((size_t)tiles_x * tiles_y, std::vector<int32_t>());
-  ok.assign((size_t)tiles_x * tiles_y, 0);
-  const V3 O = {iv[3], iv[7], iv[11]}, L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
-  auto vert = [&](size_t k, int v) { const double* q = &cur->mesh_world[9 * k + 3 * v]; return V3{q[0], q[1], q[2]}; };
-  /* every triangle as L sees it along each axis: 0 = wholly on the + side, 1 = wholly on the - side, 2 = neither */
-  struct Chart { double a0, a1, b0, b1, near; int state; };
-  std::vector<Chart> chart(3 * nt);
+  const V3 L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
+  chart.resize(3 * nt);
   for (size_t k = 0; k < nt; ++k)
     for (int m = 0; m < 3; ++m) {
-      Chart c = {1e300, -1e300, 1e300, -1e300, 1e300, 0};
+      LightChart c = {1e300, -1e300, 1e300, -1e300, 1e300, 0};
       int pos = 0, neg = 0;
       for (int v = 0; v < 3; ++v) {
-        const V3 p = vert(k, v);
-        const double q[3] = {p.x - L.x, p.y - L.y, p.z - L.z};
+        const double* w = &cur->mesh_world[9 * k + 3 * (size_t)v];
+        const double q[3] = {w[0] - L.x, w[1] - L.y, w[2] - L.z};
         const double qm = q[m];
         if (qm > pad) pos++;
         else if (qm < -pad) neg++;
@@ -765,8 +787,94 @@ void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, c
       }
       c.state = pos == 3 ? 0 : (neg == 3 ? 1 : 2);
       if (!(c.a0 <= c.a1 && c.b0 <= c.b1)) c.state = 2; /* NaN */
-      chart[3 * k + m] = c;
+      chart[3 * k + (size_t)m] = c;
     }
+}
+/* the corners of the triangles `seen` clipped to the pyramid of camera rays through the pixel rectangle [x0, x1] x
+ * [y0, y1] (margins included by the caller), appended to pts */
+void clip_to_pixel_pyramid(double x0, double x1, double y0, double y1, const std::vector<int32_t>& seen, std::vector<V3>& pts) {
+  const rt_camera& cam = cur->host_camera;
+  const double* iv = cam.inv_view;
+  const V3 O = {iv[3], iv[7], iv[11]};
+  const double cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
+  V3 d[4], dc = {0, 0, 0}, side[4];
+  for (int c = 0; c < 4; ++c) {
+    const double wx = cam.half_width - cx[c] * cam.pixel_size, wy = cam.half_height - cy[c] * cam.pixel_size;
+    d[c] = {iv[0] * wx + iv[1] * wy - iv[2], iv[4] * wx + iv[5] * wy - iv[6], iv[8] * wx + iv[9] * wy - iv[10]};
+    dc = dc + d[c];
+  }
+  for (int c = 0; c < 4; ++c) {
+    side[c] = cross(d[c], d[(c + 1) % 4]);
+    if (dot(side[c], dc) < 0) side[c] = side[c] * -1.0;
+  }
+  for (int32_t j : seen) {
+    V3 poly[16], tmp[16];
+    int np = 3;
+    for (int v = 0; v < 3; ++v) { const double* q = &cur->mesh_world[9 * (size_t)j + 3 * (size_t)v]; poly[v] = V3{q[0], q[1], q[2]}; }
+    for (int c = 0; c < 4 && np > 0; ++c) {
+      int nq = 0;
+      for (int i = 0; i < np; ++i) {
+        const V3 a = poly[i], b = poly[(i + 1) % np];
+        const double da = dot(side[c], a - O), db = dot(side[c], b - O);
+        if (da >= 0) tmp[nq++] = a;
+        if ((da >= 0) != (db >= 0)) tmp[nq++] = a + (b - a) * (da / (da - db));
+      }
+      np = nq;
+      for (int i = 0; i < np; ++i) poly[i] = tmp[i];
+    }
+    for (int i = 0; i < np; ++i) pts.push_back(poly[i]);
+  }
+}
+/* the triangles that can meet the padded hull of the points pts and the light; false: unknown (the points reach around it) */
+bool blockers_of_points(const std::vector<V3>& pts, const std::vector<LightChart>& chart, double pad, std::vector<int32_t>& blockers) {
+  const size_t nt = chart.size() / 3;
+  const V3 L = {cur->host_light[0], cur->host_light[1], cur->host_light[2]};
+  blockers.clear();
+  if (pts.empty()) return true;
+  V3 sum = {0, 0, 0};
+  for (const V3& p : pts) sum = sum + (p - L);
+  const double sa[3] = {sum.x, sum.y, sum.z};
+  int m = 0;
+  for (int c = 1; c < 3; ++c) if (std::fabs(sa[c]) > std::fabs(sa[m])) m = c;
+  const double sg = sa[m] < 0 ? -1.0 : 1.0;
+  double a0 = 1e300, a1 = -1e300, b0 = 1e300, b1 = -1e300, far = 0.0;
+  for (const V3& p : pts) {
+    const double q[3] = {p.x - L.x, p.y - L.y, p.z - L.z};
+    const double qm = sg * q[m];
+    if (!(qm > 4.0 * pad)) return false;
+    far = std::fmax(far, qm + pad);
+    for (int e = 0; e < 4; ++e) { /* the point moved by up to pad along every axis */
+      const double dq = (e & 1) ? pad : -pad, dm = (e & 2) ? pad : -pad;
+      const double a = (q[(m + 1) % 3] + dq) / (qm + dm), b = (q[(m + 2) % 3] + dq) / (qm + dm);
+      a0 = std::fmin(a0, a); a1 = std::fmax(a1, a);
+      b0 = std::fmin(b0, b); b1 = std::fmax(b1, b);
+    }
+  }
+  const double ea = 1e-9 * (1.0 + std::fmax(std::fabs(a0), std::fabs(a1))), eb = 1e-9 * (1.0 + std::fmax(std::fabs(b0), std::fabs(b1)));
+  a0 -= ea; a1 += ea; b0 -= eb; b1 += eb;
+  if (!(a0 <= a1 && b0 <= b1)) return false;
+  for (size_t k = 0; k < nt; ++k) {
+    const LightChart& c = chart[3 * k + (size_t)m];
+    if (c.state == 2) { blockers.push_back((int32_t)k); continue; }
+    if ((c.state == 0) != (sg > 0)) continue;
+    if (c.a1 >= a0 && c.a0 <= a1 && c.b1 >= b0 && c.b0 <= b1 && c.near <= far) blockers.push_back((int32_t)k);
+  }
+  return true;
+}
+/* what is_shadowed's ray can stray from the hull by: several EPSILON plus rounding at the scale of the scene */
+double shadow_pad() {
+  double reach = 1.0;
+  for (double v : cur->mesh_world) reach = std::fmax(reach, std::fabs(v));
+  for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
+  return 8.0 * RT_EPSILON + 1e-9 * reach;
+}
+void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, const std::vector<int>& y_hi,
+                       const std::vector<std::vector<int32_t>>& cam_lists, double pad, std::vector<std::vector<int32_t>>& out,
+                       std::vector<unsigned char>& ok) {
+  out.assign((size_t)tiles_x * tiles_y, std::vector<int32_t>());
+  ok.assign((size_t)tiles_x * tiles_y, 0);
+  std::vector<LightChart> chart;
+  light_charts(pad, chart);
   std::vector<V3> pts;
   for (int by = 0; by < tiles_y; by += kListShadowBlock)
     for (int bx = 0; bx < tiles_x; bx += kListShadowBlock) {
@@ -776,71 +884,11 @@ void shadow_tile_lists(int tiles_x, int tiles_y, const std::vector<int>& y_lo, c
           const std::vector<int32_t>& seen = cam_lists[(size_t)ty * tiles_x + tx];
           if (seen.empty()) continue;
           /* the tile's pyramid of rays: the directions through the corners of its (padded) pixel rectangle */
-          const double x0 = tx * (double)RT_TILE_W - 2.0, x1 = (tx + 1) * (double)RT_TILE_W + 2.0;
-          const double y0 = (double)y_lo[ty] - 2.0, y1 = (double)y_hi[ty] + 3.0;
-          const double cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
-          V3 d[4], dc = {0, 0, 0}, side[4];
-          for (int c = 0; c < 4; ++c) {
-            const double wx = cam.half_width - cx[c] * cam.pixel_size, wy = cam.half_height - cy[c] * cam.pixel_size;
-            d[c] = {iv[0] * wx + iv[1] * wy - iv[2], iv[4] * wx + iv[5] * wy - iv[6], iv[8] * wx + iv[9] * wy - iv[10]};
-            dc = dc + d[c];
-          }
-          for (int c = 0; c < 4; ++c) {
-            side[c] = cross(d[c], d[(c + 1) % 4]);
-            if (dot(side[c], dc) < 0) side[c] = side[c] * -1.0;
-          }
-          for (int32_t j : seen) {
-            V3 poly[16], tmp[16];
-            int np = 3;
-            for (int v = 0; v < 3; ++v) poly[v] = vert((size_t)j, v);
-            for (int c = 0; c < 4 && np > 0; ++c) {
-              int nq = 0;
-              for (int i = 0; i < np; ++i) {
-                const V3 a = poly[i], b = poly[(i + 1) % np];
-                const double da = dot(side[c], a - O), db = dot(side[c], b - O);
-                if (da >= 0) tmp[nq++] = a;
-                if ((da >= 0) != (db >= 0)) tmp[nq++] = a + (b - a) * (da / (da - db));
-              }
-              np = nq;
-              for (int i = 0; i < np; ++i) poly[i] = tmp[i];
-            }
-            for (int i = 0; i < np; ++i) pts.push_back(poly[i]);
-          }
+          clip_to_pixel_pyramid(tx * (double)RT_TILE_W - 2.0, (tx + 1) * (double)RT_TILE_W + 2.0, (double)y_lo[ty] - 2.0,
+                                (double)y_hi[ty] + 3.0, seen, pts);
         }
-      bool known = true;
       std::vector<int32_t> blockers;
-      if (!pts.empty()) {
-        V3 sum = {0, 0, 0};
-        for (const V3& p : pts) sum = sum + (p - L);
-        const double sa[3] = {sum.x, sum.y, sum.z};
-        int m = 0;
-        for (int c = 1; c < 3; ++c) if (std::fabs(sa[c]) > std::fabs(sa[m])) m = c;
-        const double sg = sa[m] < 0 ? -1.0 : 1.0;
-        double a0 = 1e300, a1 = -1e300, b0 = 1e300, b1 = -1e300, far = 0.0;
-        for (const V3& p : pts) {
-          const double q[3] = {p.x - L.x, p.y - L.y, p.z - L.z};
-          const double qm = sg * q[m];
-          if (!(qm > 4.0 * pad)) { known = false; break; }
-          far = std::fmax(far, qm + pad);
-          for (int e = 0; e < 4; ++e) { /* the point moved by up to pad along every axis */
-            const double dq = (e & 1) ? pad : -pad, dm = (e & 2) ? pad : -pad;
-            const double a = (q[(m + 1) % 3] + dq) / (qm + dm), b = (q[(m + 2) % 3] + dq) / (qm + dm);
-            a0 = std::fmin(a0, a); a1 = std::fmax(a1, a);
-            b0 = std::fmin(b0, b); b1 = std::fmax(b1, b);
-          }
-        }
-        if (known) {
-          const double ea = 1e-9 * (1.0 + std::fmax(std::fabs(a0), std::fabs(a1))), eb = 1e-9 * (1.0 + std::fmax(std::fabs(b0), std::fabs(b1)));
-          a0 -= ea; a1 += ea; b0 -= eb; b1 += eb;
-          if (!(a0 <= a1 && b0 <= b1)) known = false;
-          for (size_t k = 0; k < nt && known; ++k) {
-            const Chart& c = chart[3 * k + (size_t)m];
-            if (c.state == 2) { blockers.push_back((int32_t)k); continue; }
-            if ((c.state == 0) != (sg > 0)) continue;
-            if (c.a1 >= a0 && c.a0 <= a1 && c.b1 >= b0 && c.b0 <= b1 && c.near <= far) blockers.push_back((int32_t)k);
-          }
-        }
-      }
+      const bool known = blockers_of_points(pts, chart, pad, blockers);
       for (int ty = by; ty < std::min(tiles_y, by + kListShadowBlock); ++ty)
         for (int tx = bx; tx < std::min(tiles_x, bx + kListShadowBlock); ++tx) {
           const size_t tile = (size_t)ty * tiles_x + tx;
@@ -861,9 +909,52 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
                        int max_per_tile, Context::TilePlan* plan, int tiles_x) {
   std::vector<long long> start(tile_tris.size(), -1);
   size_t total = 0;
+  /* A part of a tile split into four or more is one rectangle of the tile (rt_part_rect): it gets the triangles of
+   * the tile's list that its own camera rays can reach, and, if they are few, the triangles that can stand between
+   * what those rays see and the light (a walk leaves out more than the list of a whole tile's shadow rays does, but a
+   * few pixels see little, and a short list in LDS costs less than a walk's chain of dependent steps). */
+  struct PartLists { std::vector<int32_t> cam, shadow; bool has_shadow = false; long long start = -1, sstart = -1; };
+  std::vector<PartLists> parts;
+  std::vector<int32_t> part_of((size_t)entries, -1);
+  const bool by_part = plan->part_lists && tiles_x > 0 && cur->tri_xy.size() == 6 * (size_t)cur->scene.n_tris &&
+                       cur->mesh_world.size() == 9 * (size_t)cur->scene.n_tris;
+  std::vector<LightChart> chart;
+  std::vector<V3> pts;
+  const double pad = by_part ? shadow_pad() : 0.0;
   for (int e = 0; e < entries; ++e) {
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
     if (tile >= tile_tris.size()) return false;
+    const int lg = RT_ENTRY_LG(list[e]);
+    if (by_part && e < heavy && lg >= 2 && !tile_tris[tile].empty()) {
+      int rx, ry, rw, rh;
+      rt_part_rect(lg, RT_ENTRY_PART(list[e]), rx, ry, rw, rh);
+      const int r0 = (int)(tile / (size_t)tiles_x) * RT_TILE_H + ry, r1 = std::min(plan->rows, r0 + rh) - 1;
+      PartLists pl;
+      bool own = true;
+      if (r1 >= r0) {
+        const double x0 = (double)((int)(tile % (size_t)tiles_x) * RT_TILE_W + rx), x1 = x0 + rw;
+        const double y0 = (double)rt_hip_rank_row_to_y(r0, plan->band_rows, plan->n_ranks, plan->rank);
+        const double y1 = (double)rt_hip_rank_row_to_y(r1, plan->band_rows, plan->n_ranks, plan->rank) + 1.0;
+        for (int32_t k : tile_tris[tile])
+          if (tri_reaches_rect((size_t)k, x0, x1, y0, y1)) pl.cam.push_back(k);
+        own = pl.cam.size() <= (size_t)max_per_tile;
+        if (own && plan->part_shadow_max > 0 && !pl.cam.empty()) {
+          if (chart.empty()) light_charts(pad, chart);
+          pts.clear();
+          clip_to_pixel_pyramid(x0 - 2.0, x1 + 2.0, y0 - 2.0, y1 + 2.0, pl.cam, pts);
+          pl.has_shadow = blockers_of_points(pts, chart, pad, pl.shadow) && pl.shadow.size() <= (size_t)plan->part_shadow_max;
+          if (!pl.has_shadow) pl.shadow.clear();
+        }
+      }
+      if (own && total + pl.cam.size() + pl.shadow.size() <= kMaxListEntries / 2) {
+        pl.start = (long long)total;
+        total += pl.cam.size();
+        if (pl.has_shadow) { pl.sstart = (long long)total; total += pl.shadow.size(); }
+        part_of[(size_t)e] = (int32_t)parts.size();
+        parts.push_back(std::move(pl));
+        continue;
+      }
+    }
     if (start[tile] >= 0 || tile_tris[tile].size() > (size_t)max_per_tile) continue;
     start[tile] = (long long)total;
     total += tile_tris[tile].size();
@@ -877,9 +968,15 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
   if (total == 0 || total > kMaxListEntries) return false;
   for (int e = 0; e < heavy && e < entries; ++e) {
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
-    if (start[tile] >= 0) plan->list_longest = std::max(plan->list_longest, (int)tile_tris[tile].size());
+    if (part_of[(size_t)e] >= 0) {
+      const PartLists& pl = parts[(size_t)part_of[(size_t)e]];
+      plan->list_longest = std::max(plan->list_longest, (int)pl.cam.size());
+      plan->shadow_longest = std::max(plan->shadow_longest, (int)pl.shadow.size());
+    } else if (start[tile] >= 0) {
+      plan->list_longest = std::max(plan->list_longest, (int)tile_tris[tile].size());
+    }
   }
-  /* the shadow rays' lists: one per block of tiles (the tiles of a block share it), behind the camera rays' */
+  /* the shadow rays' lists of whole tiles: one per block of tiles (the tiles of a block share it), behind the camera rays' */
   const bool shadows = plan->tile_shadow.size() == tile_tris.size() && plan->tile_shadow_ok.size() == tile_tris.size() && tiles_x > 0;
   const int bx_n = (tiles_x + kListShadowBlock - 1) / kListShadowBlock;
   std::vector<long long> shadow_start_of_block;
@@ -889,7 +986,7 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
     shadow_start_of_block.assign((size_t)bx_n * ((tiles_y + kListShadowBlock - 1) / kListShadowBlock + 1), -1);
     for (int e = 0; e < entries; ++e) {
       const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
-      if (shadow_start[tile] >= 0 || !plan->tile_shadow_ok[tile] || tile_tris[tile].empty()) continue;
+      if (part_of[(size_t)e] >= 0 || shadow_start[tile] >= 0 || !plan->tile_shadow_ok[tile] || tile_tris[tile].empty()) continue;
       const std::vector<int32_t>& sl = plan->tile_shadow[tile];
       if (sl.size() > (size_t)plan->shadow_max || total + sl.size() > kMaxListEntries) continue;
       const size_t blk = (size_t)((int)(tile / (size_t)tiles_x) / kListShadowBlock) * bx_n + (size_t)((int)(tile % (size_t)tiles_x) / kListShadowBlock);
@@ -902,31 +999,47 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
     }
   }
   if (getenv("RT_HIP_VERBOSE")) {
-    int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0}, with_shadow = 0;
-    size_t shadow_sum = 0;
+    int longest_any = 0, n_over[5] = {0, 0, 0, 0, 0}, with_shadow = 0, n_parts = 0, parts_with_shadow = 0;
+    size_t shadow_sum = 0, part_sum = 0, part_shadow_sum = 0;
     for (int e = 0; e < heavy && e < entries; ++e) {
       const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
+      if (part_of[(size_t)e] >= 0) {
+        const PartLists& pl = parts[(size_t)part_of[(size_t)e]];
+        n_parts++;
+        part_sum += pl.cam.size();
+        if (pl.has_shadow) { parts_with_shadow++; part_shadow_sum += pl.shadow.size(); }
+        continue;
+      }
       const int n = (int)tile_tris[tile].size();
       longest_any = std::max(longest_any, n);
       n_over[n > 512 ? 4 : (n > 256 ? 3 : (n > 128 ? 2 : (n > 64 ? 1 : 0)))]++;
       if (shadows && shadow_start[tile] >= 0) { with_shadow++; shadow_sum += plan->tile_shadow[tile].size(); }
     }
     fprintf(stderr, "tile lists: %zu forms, longest list in use %d (of any mesh tile: %d), mesh entries with <=64/128/256/512/more: %d %d %d %d %d; "
-                    "shadow lists for %d mesh entries, mean %.1f, longest %d\n",
+                    "shadow lists for %d mesh entries, mean %.1f, longest %d; %d parts with lists of their own (mean %.1f), %d of them with shadow lists (mean %.1f)\n",
             total, plan->list_longest, longest_any, n_over[0], n_over[1], n_over[2], n_over[3], n_over[4], with_shadow,
-            with_shadow ? (double)shadow_sum / with_shadow : 0.0, plan->shadow_longest);
+            with_shadow ? (double)shadow_sum / with_shadow : 0.0, plan->shadow_longest, n_parts, n_parts ? (double)part_sum / n_parts : 0.0,
+            parts_with_shadow, parts_with_shadow ? (double)part_shadow_sum / parts_with_shadow : 0.0);
   }
   list.resize((size_t)entries);
   if (list.size() % 2) list.push_back(0);
   plan->mask_offset = list.size();
   for (int e = 0; e < entries; ++e) {
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
-    const bool has = start[tile] >= 0;
-    list.push_back(has ? (int32_t)(uint32_t)start[tile] : 0);
-    list.push_back(has ? (int32_t)tile_tris[tile].size() : -1);
-    const bool hs = shadows && shadow_start[tile] >= 0;
-    list.push_back(hs ? (int32_t)(uint32_t)shadow_start[tile] : 0);
-    list.push_back(hs ? (int32_t)plan->tile_shadow[tile].size() : -1);
+    if (part_of[(size_t)e] >= 0) {
+      const PartLists& pl = parts[(size_t)part_of[(size_t)e]];
+      list.push_back((int32_t)(uint32_t)pl.start);
+      list.push_back((int32_t)pl.cam.size());
+      list.push_back(pl.has_shadow ? (int32_t)(uint32_t)pl.sstart : 0);
+      list.push_back(pl.has_shadow ? (int32_t)pl.shadow.size() : -1);
+    } else {
+      const bool has = start[tile] >= 0;
+      list.push_back(has ? (int32_t)(uint32_t)start[tile] : 0);
+      list.push_back(has ? (int32_t)tile_tris[tile].size() : -1);
+      const bool hs = shadows && shadow_start[tile] >= 0;
+      list.push_back(hs ? (int32_t)(uint32_t)shadow_start[tile] : 0);
+      list.push_back(hs ? (int32_t)plan->tile_shadow[tile].size() : -1);
+    }
     for (int k = 0; k < 4; ++k) list.push_back(0);
   }
   while (list.size() % 16) list.push_back(0);
@@ -951,6 +1064,10 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
       const std::vector<int32_t>& l = plan->tile_shadow[tile];
       for (size_t k = 0; k < l.size(); ++k) put((size_t)shadow_start[tile] + k, l[k], false);
     }
+  }
+  for (const PartLists& pl : parts) {
+    for (size_t k = 0; k < pl.cam.size(); ++k) put((size_t)pl.start + k, pl.cam[k], true);
+    for (size_t k = 0; k < pl.shadow.size(); ++k) put((size_t)pl.sstart + k, pl.shadow[k], false);
   }
   return true;
 }
@@ -1232,7 +1349,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       for (int32_t tile : heavy) {
         if (cost_of_tile[tile] >= floor_cost) {
           const int parts = cost_of_tile[tile] >= floor_cost4 ? 4 : cur->split_parts;
-          for (int part = 0; part < parts; ++part) split.push_back(tile | (part << 24) | ((parts == 4 ? 2 : 1) << 28));
+          for (int part = 0; part < parts; ++part) split.push_back(RT_ENTRY(tile, part, parts == 4 ? 2 : 1));
         } else {
           split.push_back(tile);
         }
@@ -1261,11 +1378,14 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       plan->tile_shadow.clear();
       plan->tile_shadow_ok.clear();
       plan->shadow_max = bvh ? 0 : 0x7fffffff;
+      plan->part_lists = bvh && cur->part_lists;
+      plan->part_shadow_max = cur->shadow_lists ? cur->part_shadow_max : 0;
+      plan->rows = rows;
+      plan->band_rows = p->n_ranks > 1 ? p->band_rows : 1;
+      plan->n_ranks = p->n_ranks;
+      plan->rank = p->rank;
       if (cur->shadow_lists && plan->shadow_max > 0 && cur->mesh_world.size() == 9 * (size_t)cur->scene.n_tris) {
-        double reach = 1.0;
-        for (double v : cur->mesh_world) reach = std::fmax(reach, std::fabs(v));
-        for (int c = 0; c < 3; ++c) reach = std::fmax(reach, std::fmax(std::fabs(cur->host_light[c]), std::fabs(cur->host_camera.inv_view[4 * c + 3])));
-        shadow_tile_lists(tiles_x, tiles_y, y_lo, y_hi, tri_lists, 8.0 * RT_EPSILON + 1e-9 * reach, plan->tile_shadow, plan->tile_shadow_ok);
+        shadow_tile_lists(tiles_x, tiles_y, y_lo, y_hi, tri_lists, shadow_pad(), plan->tile_shadow, plan->tile_shadow_ok);
       }
       if (!append_tile_lists(heavy, plan->entries, plan->heavy, tri_lists, bvh ? (few_tiles ? cur->list_max_walk_few : cur->list_max_walk) : 0x7fffffff, plan, tiles_x))
         want_lists = false;
@@ -1714,9 +1834,19 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     const double even = (double)total / slots; /* cycles of a launch whose waves fill every slot to the end */
     if (getenv("RT_HIP_VERBOSE")) {
       int by_lg[5] = {0, 0, 0, 0, 0};
-      for (int i = 0; i < nh; ++i) by_lg[std::min(4, (list[i] >> 28) & 7)]++;
+      for (int i = 0; i < nh; ++i) by_lg[std::min(4, RT_ENTRY_LG(list[i]))]++;
       fprintf(stderr, "refine_split round %d: %.1f us, %d mesh entries (parts 1/2/4/8/16: %d %d %d %d %d), slowest wave %u cycles, even %.0f\n",
               round, ms * 1e3, nh, by_lg[0], by_lg[1], by_lg[2], by_lg[3], by_lg[4], slowest, even);
+      std::vector<int> idx((size_t)nh);
+      for (int i = 0; i < nh; ++i) idx[i] = i;
+      std::partial_sort(idx.begin(), idx.begin() + std::min(nh, 5), idx.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+      for (int q = 0; q < std::min(nh, 5); ++q) {
+        const int i = idx[q], tile = list[i] & RT_TILE_MASK;
+        fprintf(stderr, "  slow entry at position %d: tile %d (x %d, y %d), part %d of 2^%d, list of %zu, waves %u %u %u %u cycles\n", i, tile,
+                tile % ((cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W), tile / ((cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W), RT_ENTRY_PART(list[i]),
+                RT_ENTRY_LG(list[i]), (size_t)tile < plan->tile_tris.size() ? plan->tile_tris[(size_t)tile].size() : (size_t)0, cyc[(size_t)i * 4],
+                cyc[(size_t)i * 4 + 1], cyc[(size_t)i * 4 + 2], cyc[(size_t)i * 4 + 3]);
+      }
     }
     if (round == rounds || (double)slowest <= 1.15 * even) break;
     const double threshold = std::max(even, 0.5 * (double)slowest);
@@ -1726,10 +1856,10 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     bool any = false;
     for (int i = 0; i < nh; ++i) {
       const int32_t entry = list[i];
-      const int lg = (entry >> 28) & 7, part = (entry >> 24) & 15;
-      if ((double)cost[i] > threshold && lg < 4) {
+      const int lg = RT_ENTRY_LG(entry), part = RT_ENTRY_PART(entry);
+      if ((double)cost[i] > threshold && lg < cur->split_max_lg) {
         const int32_t tile = entry & RT_TILE_MASK;
-        for (int h = 0; h < 2; ++h) items.push_back({tile | ((2 * part + h) << 24) | ((lg + 1) << 28), 0.6 * cost[i]});
+        for (int h = 0; h < 2; ++h) items.push_back({RT_ENTRY(tile, 2 * part + h, lg + 1), 0.6 * cost[i]});
         any = true;
       } else {
         items.push_back({entry, (double)cost[i]});
@@ -2152,6 +2282,9 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) cur->split_min_cost = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_REFINE")) cur->split_refine = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_PART_SHADOW_MAX")) cur->part_shadow_max = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_SPLIT_MAX_LG")) cur->split_max_lg = std::max(0, std::min(6, atoi(e)));
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */

@@ -30,7 +30,8 @@ t0 = w0.min()
 start_us, end_us = (w0 - t0) / 100.0, (w1 - t0) / 100.0
 dur_us = end_us - start_us
 cyc = (s[:, 1] - s[:, 0])
-heavy = s[:, 5] == 1
+heavy = (s[:, 5] & 1) == 1
+entry = (s[:, 5] >> 8) & 0xffffffff
 xcc = (s[:, 4] >> 32) & 0xF
 print(f"{scene}: {used.sum()} waves recorded, {heavy.sum()} in heavy workgroups")
 print(f"last wave ends {end_us.max():.2f} us after the first starts; starts: median {np.median(start_us):.2f}, 90% {np.percentile(start_us, 90):.2f}, max {start_us.max():.2f} us")
@@ -41,16 +42,19 @@ for name, m in (("heavy", heavy), ("light", ~heavy)):
               f"start median {np.median(start_us[m]):.2f}, max {start_us[m].max():.2f}; end max {end_us[m].max():.2f}; "
               f"shader-clock/wall ratio {np.median(cyc[m] / np.maximum(dur_us[m], 0.01)):.0f} ticks/us")
 if WORDS > 6:  # -DRT_PHASES=1: shader-clock ticks per phase, summed over the heavy waves
-    ph = s[heavy][:, 6:14].astype(np.float64)
+    ph = s[heavy][:, 6:13].astype(np.float64)
     names = ["ray generation", "nearest hit", "hit point, shadow ray", "shadow ray", "lighting", "store", "start-up, staging", "-"]
     tot = ph.sum()
     print("phases of heavy waves (share of their ticks; median ticks per wave):",
           [(names[k], round(float(ph[:, k].sum() / tot), 3), int(np.median(ph[:, k]))) for k in range(7)])
 if WORDS > 6:  # the waves that end last: where their ticks went
-    order = np.argsort(-end_us)[:6]
+    order = np.argsort(-end_us)[:12]
     for i in order:
-        print(f"  wave ending at {end_us[i]:.2f} us (started {start_us[i]:.2f}, heavy {int(s[i, 5])}): ticks per phase",
-              [int(x) for x in s[i, 6:13]])
+        e = int(entry[i])
+        tal = int(s[i, 13])
+        print(f"  wave ending at {end_us[i]:.2f} us (started {start_us[i]:.2f}, heavy {int(s[i, 5]) & 1}, tile {e & 0x3fffff} part {(e >> 22) & 63} of 2^{(e >> 28) & 7}): ticks per phase",
+              [int(x) for x in s[i, 6:13]], "most per lane: camera-list confirms, shadow-list confirms, walk steps, leaf tests",
+              [(tal >> (16 * k)) & 0xffff for k in range(4)])
 print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
 hist, edges = np.histogram(end_us, bins=12)
 print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
