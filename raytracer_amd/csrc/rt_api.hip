@@ -76,7 +76,8 @@ struct Context {
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
   int part_shadow_max = 96; /* ... and lists for their shadow rays up to this length (0: none) */
-  int split_max_lg = 4;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave) */
+  int split_max_lg = 5;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
+                               lighthouse with mirrors 135 us with 4, 126 us with 5 or 6, 1080p the same with all three */
   bool split_resort = true; /* after the refinement: the winning list once more, in the order of its own measurement */
   int split_refine = 3;    /* launches that measure their waves and split the slowest tiles further */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
@@ -1734,7 +1735,7 @@ int check_params(const rt_render_params* p) {
  * are all resident at once lasts as long as its slowest wave, so the first launch with a new plan measures instead:
  * every wave of a mesh tile's workgroup reports its cycle count, tiles whose slowest wave runs longer than the
  * launch could take if its work were spread evenly (and longer than half the slowest of all) are split into twice
- * as many parts (down to 4 x 1 pixels per wave), and the list is re-ordered longest first by what was measured.
+ * as many parts (down to 2 x 1 pixels per wave), and the list is re-ordered longest first by what was measured.
  * Up to split_refine rounds.  Every candidate list is a real render into the caller's image, timed with events; the
  * list with the shortest launch is the one the plan keeps (a later one has to win by 2 %: mirror frames, whose
  * lanes part ways after the first bounce, gain 25 % from finer parts, while a frame of primary and shadow rays
@@ -1776,7 +1777,6 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     a.list_total = (int32_t)plan->list_total;
     a.list_lds = plan->list_forms && cur->list_lds ? (std::min(plan->list_longest, kMaxLdsListForms) + 3) / 4 * 4 : 0;
     a.slist_lds = plan->list_forms && cur->list_lds ? (std::min(plan->shadow_longest, kMaxLdsShadowForms) + 3) / 4 * 4 : 0;
-  a.slist_lds = plan->list_forms && cur->list_lds ? (std::min(plan->shadow_longest, kMaxLdsShadowForms) + 3) / 4 * 4 : 0;
     a.n_heavy = plan->heavy;
     a.n_entries = plan->entries;
     n_blocks = plan_blocks(plan);
