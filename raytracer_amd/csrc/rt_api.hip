@@ -19,6 +19,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "rt_kernels.hip.inc"
@@ -76,10 +77,11 @@ struct Context {
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
   int part_shadow_max = 96; /* ... and lists for their shadow rays up to this length (0: none) */
-  int split_max_lg = 5;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
+  double split_threshold = 0.85; /* the refinement splits the entries whose slowest wave ran longer than this share of the slowest of all */
+  int split_max_lg = 6;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
                                lighthouse with mirrors 135 us with 4, 126 us with 5 or 6, 1080p the same with all three */
   bool split_resort = true; /* after the refinement: the winning list once more, in the order of its own measurement */
-  int split_refine = 3;    /* launches that measure their waves and split the slowest tiles further */
+  int split_refine = 10;    /* launches that measure their waves and split the slowest tiles further */
   int xcd_tiles = -1;      /* mesh tiles in per-XCD runs: 0 never, 1 always, -1 when the tree is read from memory */
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; /* per-call kernel time (rt_stats) */
@@ -130,6 +132,8 @@ struct Context {
     std::vector<std::vector<int32_t>> tile_shadow; /* by tile number: the triangles of its shadow rays' list (with tile_tris) */
     std::vector<unsigned char> tile_shadow_ok;     /* by tile number: 1 = tile_shadow holds every possible blocker, 0 = unknown */
     int shadow_max = 0, shadow_longest = 0;        /* as list_max / list_longest */
+    struct PartLists { std::vector<int32_t> cam, shadow; bool own = false, has_shadow = false; long long start = -1, sstart = -1; };
+    std::unordered_map<int32_t, PartLists> part_cache; /* by entry: the lists of parts made so far (while refinements are pending) */
     bool part_lists = false;       /* walks: a part of a tile split into four or more gets lists of its own rectangle */
     int part_shadow_max = 0;       /* ... and a shadow rays' list if that has at most this many triangles */
     int rows = 0, band_rows = 1, n_ranks = 1, rank = 0; /* the launch's packed rows and how they map to image rows */
@@ -914,7 +918,7 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
    * the tile's list that its own camera rays can reach, and, if they are few, the triangles that can stand between
    * what those rays see and the light (a walk leaves out more than the list of a whole tile's shadow rays does, but a
    * few pixels see little, and a short list in LDS costs less than a walk's chain of dependent steps). */
-  struct PartLists { std::vector<int32_t> cam, shadow; bool has_shadow = false; long long start = -1, sstart = -1; };
+  typedef Context::TilePlan::PartLists PartLists;
   std::vector<PartLists> parts;
   std::vector<int32_t> part_of((size_t)entries, -1);
   const bool by_part = plan->part_lists && tiles_x > 0 && cur->tri_xy.size() == 6 * (size_t)cur->scene.n_tris &&
@@ -930,23 +934,30 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
       int rx, ry, rw, rh;
       rt_part_rect(lg, RT_ENTRY_PART(list[e]), rx, ry, rw, rh);
       const int r0 = (int)(tile / (size_t)tiles_x) * RT_TILE_H + ry, r1 = std::min(plan->rows, r0 + rh) - 1;
-      PartLists pl;
-      bool own = true;
-      if (r1 >= r0) {
-        const double x0 = (double)((int)(tile % (size_t)tiles_x) * RT_TILE_W + rx), x1 = x0 + rw;
-        const double y0 = (double)rt_hip_rank_row_to_y(r0, plan->band_rows, plan->n_ranks, plan->rank);
-        const double y1 = (double)rt_hip_rank_row_to_y(r1, plan->band_rows, plan->n_ranks, plan->rank) + 1.0;
-        for (int32_t k : tile_tris[tile])
-          if (tri_reaches_rect((size_t)k, x0, x1, y0, y1)) pl.cam.push_back(k);
-        own = pl.cam.size() <= (size_t)max_per_tile;
-        if (own && plan->part_shadow_max > 0 && !pl.cam.empty()) {
-          if (chart.empty()) light_charts(pad, chart);
-          pts.clear();
-          clip_to_pixel_pyramid(x0 - 2.0, x1 + 2.0, y0 - 2.0, y1 + 2.0, pl.cam, pts);
-          pl.has_shadow = blockers_of_points(pts, chart, pad, pl.shadow) && pl.shadow.size() <= (size_t)plan->part_shadow_max;
-          if (!pl.has_shadow) pl.shadow.clear();
+      auto cached = plan->part_cache.find(list[e]);
+      if (cached == plan->part_cache.end()) {
+        PartLists fresh;
+        fresh.own = true;
+        if (r1 >= r0) {
+          const double x0 = (double)((int)(tile % (size_t)tiles_x) * RT_TILE_W + rx), x1 = x0 + rw;
+          const double y0 = (double)rt_hip_rank_row_to_y(r0, plan->band_rows, plan->n_ranks, plan->rank);
+          const double y1 = (double)rt_hip_rank_row_to_y(r1, plan->band_rows, plan->n_ranks, plan->rank) + 1.0;
+          for (int32_t k : tile_tris[tile])
+            if (tri_reaches_rect((size_t)k, x0, x1, y0, y1)) fresh.cam.push_back(k);
+          fresh.own = fresh.cam.size() <= (size_t)max_per_tile;
+          if (fresh.own && plan->part_shadow_max > 0 && !fresh.cam.empty()) {
+            if (chart.empty()) light_charts(pad, chart);
+            pts.clear();
+            clip_to_pixel_pyramid(x0 - 2.0, x1 + 2.0, y0 - 2.0, y1 + 2.0, fresh.cam, pts);
+            fresh.has_shadow = blockers_of_points(pts, chart, pad, fresh.shadow) && fresh.shadow.size() <= (size_t)plan->part_shadow_max;
+            if (!fresh.has_shadow) fresh.shadow.clear();
+          }
+          if (!fresh.own) fresh.cam.clear();
         }
+        cached = plan->part_cache.emplace(list[e], std::move(fresh)).first;
       }
+      PartLists pl = cached->second;
+      const bool own = pl.own;
       if (own && total + pl.cam.size() + pl.shadow.size() <= kMaxListEntries / 2) {
         pl.start = (long long)total;
         total += pl.cam.size();
@@ -1379,6 +1390,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       plan->tile_shadow.clear();
       plan->tile_shadow_ok.clear();
       plan->shadow_max = bvh ? 0 : 0x7fffffff;
+      plan->part_cache.clear();
       plan->part_lists = bvh && cur->part_lists;
       plan->part_shadow_max = cur->shadow_lists ? cur->part_shadow_max : 0;
       plan->rows = rows;
@@ -1436,6 +1448,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
     if (plan->refine_left > 0) plan->host_list = entries_only.empty() ? heavy : entries_only;
     else plan->host_list.clear();
     if (plan->refine_left <= 0 || !plan->list_forms) {
+      plan->part_cache.clear();
       plan->tile_tris.clear(); plan->tile_tris.shrink_to_fit();
       plan->tile_shadow.clear(); plan->tile_shadow.shrink_to_fit();
       plan->tile_shadow_ok.clear();
@@ -1733,13 +1746,15 @@ int check_params(const rt_render_params* p) {
 
 /* The split of plan_tiles goes by a static estimate (triangles that project into a tile).  A frame whose mesh tiles
  * are all resident at once lasts as long as its slowest wave, so the first launch with a new plan measures instead:
- * every wave of a mesh tile's workgroup reports its cycle count, tiles whose slowest wave runs longer than the
- * launch could take if its work were spread evenly (and longer than half the slowest of all) are split into twice
- * as many parts (down to 2 x 1 pixels per wave), and the list is re-ordered longest first by what was measured.
- * Up to split_refine rounds.  Every candidate list is a real render into the caller's image, timed with events; the
- * list with the shortest launch is the one the plan keeps (a later one has to win by 2 %: mirror frames, whose
- * lanes part ways after the first bounce, gain 25 % from finer parts, while a frame of primary and shadow rays
- * alone walks nearly the same path in every lane of a tile and only pays for the extra workgroups). */
+ * every wave of a mesh tile's workgroup reports its cycle count, the entries whose slowest wave runs longer than the
+ * launch could take if its work were spread evenly, and longer than split_threshold of the slowest of all, are split
+ * into twice as many parts (down to one pixel per wave), and the list is re-ordered longest first by what was
+ * measured.  Only the few slowest are split in a round, and there are up to split_refine rounds: a part costs a
+ * workgroup with its staging whatever it renders, and halving the pixels of a wave shortens it by far less than half
+ * (the wave walks the union of its lanes' paths), so splitting everything that is slower than half the slowest, in
+ * three rounds, ended with more work than it saved (1080p lighthouse 40.5 us; 31.4 us this way).  Every candidate
+ * list is a real render into the caller's image, timed with events; the list with the shortest launch is the one the
+ * plan keeps (a later one has to win by 2 %), and three rounds in a row that do not win end the search. */
 int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s, RenderArgs& a, unsigned char* d_rgb,
                  double* d_canvas, int& n_blocks) {
   int slots = cur->n_cu * 4 * (reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN);
@@ -1758,6 +1773,7 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   float best_ms = 1e30f;
   std::vector<unsigned> best_cost; /* the slowest wave of every mesh entry of best_list, as measured with that list */
   bool current_is_best = true;
+  int stale = 0; /* rounds in a row that did not win */
   int rc = RT_OK;
   const bool with_lists = plan->list_forms != 0 && !plan->tile_tris.empty();
   auto adopt = [&](const std::vector<int32_t>& l) {
@@ -1821,8 +1837,10 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
       best_list = list;
       best_cost = cost;
       current_is_best = true;
+      stale = 0;
     } else {
       current_is_best = false;
+      stale++;
     }
     /* wave slots of the chip for this kernel: a workgroup is one wave per SIMD, and the LDS it asks for may allow
      * fewer workgroups per CU than the registers do */
@@ -1848,8 +1866,8 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
                 cyc[(size_t)i * 4 + 1], cyc[(size_t)i * 4 + 2], cyc[(size_t)i * 4 + 3]);
       }
     }
-    if (round == rounds || (double)slowest <= 1.15 * even) break;
-    const double threshold = std::max(even, 0.5 * (double)slowest);
+    if (round == rounds || (double)slowest <= 1.15 * even || stale >= 3) break;
+    const double threshold = std::max(even, cur->split_threshold * (double)slowest);
     struct Item { int32_t entry; double cost; };
     std::vector<Item> items;
     items.reserve((size_t)nh * 2);
@@ -1911,6 +1929,7 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     }
   }
   if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
+  plan->part_cache.clear();
   plan->tile_tris.clear();
   plan->tile_tris.shrink_to_fit();
   plan->tile_shadow.clear();
@@ -2284,6 +2303,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_PART_SHADOW_MAX")) cur->part_shadow_max = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_SPLIT_THRESHOLD")) cur->split_threshold = std::fmax(0.1, std::fmin(0.99, atof(e)));
   if (const char* e = getenv("RT_HIP_SPLIT_MAX_LG")) cur->split_max_lg = std::max(0, std::min(6, atoi(e)));
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
