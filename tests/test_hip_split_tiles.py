@@ -2,7 +2,9 @@
 split, every pixel is traced exactly once and the image equals the exhaustive loop's and the oracle's.  The same
 holds with and without the per-tile triangle lists that camera rays run down instead of walking the tree (none,
 for every tile, only for tiles with at most 8 triangles), and of the lists of possible blockers that the shadow rays
-run down."""
+run down.  A part of a tile split into four or more is one rectangle of the tile and has lists of its own (camera rays
+and, if short, shadow rays): with and without them, with every part given a shadow list however long, and with a
+refinement that splits nearly everything down to single pixels per wave."""
 import json
 import os
 import subprocess
@@ -20,7 +22,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                         (4, 100000, 1, {"RT_HIP_LIST_MAX_WALK": "8"}),
                                                         (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "100000"}),
                                                         (2, 100000, 1, {"RT_HIP_SHADOW_LISTS": "0"}),
-                                                        (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "24", "RT_HIP_LIST_LDS": "0"})])
+                                                        (1, 0, 1, {"RT_HIP_LIST_MAX_WALK": "24", "RT_HIP_LIST_LDS": "0"}),
+                                                        (4, 100000, 1, {"RT_HIP_PART_LISTS": "0"}),
+                                                        (4, 100000, 1, {"RT_HIP_PART_SHADOW_MAX": "0", "RT_HIP_SPLIT_MAX_LG": "4"}),
+                                                        (4, 100000, 1, {"RT_HIP_PART_SHADOW_MAX": "100000", "RT_HIP_SPLIT_THRESHOLD": "0.2",
+                                                                        "RT_HIP_LIST_MAX_WALK": "100000"}),
+                                                        (2, 100000, 1, {"RT_HIP_SPLIT_THRESHOLD": "0.3", "RT_HIP_SPLIT_REFINE": "12",
+                                                                        "RT_HIP_LIST_LDS": "0"})])
 def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost, lists):
     env = dict(os.environ, RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
     r = subprocess.run([sys.executable, os.path.join(HERE, "split_tiles_child.py")], env=env, capture_output=True, text=True,
