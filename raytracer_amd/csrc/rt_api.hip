@@ -76,6 +76,8 @@ struct Context {
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
+  int part_min_lg = 2;      /* entries split into at least 2^this parts get lists of their own */
+  int walk_shadow_max = 0;  /* walks: a whole tile's shadow rays run down their block's list if it has at most this many triangles */
   int part_shadow_max = 96; /* ... and lists for their shadow rays up to this length (0: none) */
   double split_threshold = 0.85; /* the refinement splits the entries whose slowest wave ran longer than this share of the slowest of all */
   int split_max_lg = 6;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
@@ -930,7 +932,7 @@ bool append_tile_lists(std::vector<int32_t>& list, int entries, int heavy, const
     const size_t tile = (size_t)(list[e] & RT_TILE_MASK);
     if (tile >= tile_tris.size()) return false;
     const int lg = RT_ENTRY_LG(list[e]);
-    if (by_part && e < heavy && lg >= 2 && !tile_tris[tile].empty()) {
+    if (by_part && e < heavy && lg >= cur->part_min_lg && !tile_tris[tile].empty()) {
       int rx, ry, rw, rh;
       rt_part_rect(lg, RT_ENTRY_PART(list[e]), rx, ry, rw, rh);
       const int r0 = (int)(tile / (size_t)tiles_x) * RT_TILE_H + ry, r1 = std::min(plan->rows, r0 + rh) - 1;
@@ -1389,7 +1391,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
       const bool few_tiles = (size_t)plan->heavy <= (size_t)(cur->split_max_per_cu + 2) * cur->n_cu && !overlap;
       plan->tile_shadow.clear();
       plan->tile_shadow_ok.clear();
-      plan->shadow_max = bvh ? 0 : 0x7fffffff;
+      plan->shadow_max = bvh ? cur->walk_shadow_max : 0x7fffffff;
       plan->part_cache.clear();
       plan->part_lists = bvh && cur->part_lists;
       plan->part_shadow_max = cur->shadow_lists ? cur->part_shadow_max : 0;
@@ -2301,6 +2303,8 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_MIN_COST")) cur->split_min_cost = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_REFINE")) cur->split_refine = atoi(e);
   if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_WALK_SHADOW_MAX")) cur->walk_shadow_max = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_PART_MIN_LG")) cur->part_min_lg = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_PART_SHADOW_MAX")) cur->part_shadow_max = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_SPLIT_THRESHOLD")) cur->split_threshold = std::fmax(0.1, std::fmin(0.99, atof(e)));
