@@ -78,7 +78,9 @@ struct Context {
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
   int part_min_lg = 2;      /* entries split into at least 2^this parts get lists of their own */
   int walk_shadow_max = 0;  /* walks: a whole tile's shadow rays run down their block's list if it has at most this many triangles */
-  int part_shadow_max = 96; /* ... and lists for their shadow rays up to this length (0: none) */
+  int part_shadow_max = 0;  /* ... and lists for their shadow rays up to this length (0: none, the default: with lists of
+                               up to 48 or 96 the lighthouse frames are the same to the microsecond, and making them costs
+                               3-4 ms when the tiles are planned; from 256 up the frames get slower) */
   double split_threshold = 0.85; /* the refinement splits the entries whose slowest wave ran longer than this share of the slowest of all */
   int split_max_lg = 6;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
                                lighthouse with mirrors 135 us with 4, 126 us with 5 or 6, 1080p the same with all three */
