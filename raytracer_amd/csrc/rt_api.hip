@@ -144,6 +144,7 @@ struct Context {
     size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
                                       ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
     int refine_left = 0;           /* measured refinements of the split still to do (see refine_split) */
+    bool refining = false;         /* refine_split is at work on this plan */
     std::vector<int32_t> host_list; /* the list as uploaded, kept while refinements are pending */
     unsigned long long last_use = 0;
   };
@@ -480,8 +481,10 @@ int store_plan(Context::TilePlan* t, const long long key[6], const std::vector<i
     if (t->d_list) (void)hipFree(t->d_list);
     t->d_list = nullptr;
     t->cap = 0;
-    HIP_TRY(hipMalloc((void**)&t->d_list, sizeof(int32_t) * list.size()));
-    t->cap = list.size();
+    /* a plan whose split is still being refined is stored again with a longer list every round: room for that */
+    const size_t want = t->refine_left > 0 || t->refining ? list.size() * 2 : list.size();
+    HIP_TRY(hipMalloc((void**)&t->d_list, sizeof(int32_t) * want));
+    t->cap = want;
   }
   HIP_TRY(hipMemcpyAsync(t->d_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s)); /* the host vector goes away */
@@ -1764,16 +1767,17 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   int slots = cur->n_cu * 4 * (reflect ? RT_MIN_WAVES_BVH : RT_MIN_WAVES_BVH_PLAIN);
   const int rounds = plan->refine_left;
   plan->refine_left = 0;
+  plan->refining = true;
   const int n_light = plan->entries - plan->heavy;
   std::vector<int32_t> list = plan->host_list, best_list = list;
   plan->host_list.clear();
   plan->host_list.shrink_to_fit();
-  if (list.empty()) return RT_OK;
+  if (list.empty()) { plan->refining = false; return RT_OK; }
   long long key[6];
   memcpy(key, plan->key, sizeof key);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
-  if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return RT_ERR_HIP; }
+  if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); plan->refining = false; return RT_ERR_HIP; }
   float best_ms = 1e30f;
   std::vector<unsigned> best_cost; /* the slowest wave of every mesh entry of best_list, as measured with that list */
   bool current_is_best = true;
@@ -1802,10 +1806,16 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     n_blocks = plan_blocks(plan);
     return (int)RT_OK;
   };
+  unsigned* d_probe = nullptr; /* four words per mesh entry; made once, with room for the entries that the rounds add */
+  size_t probe_cap = 0;
   for (int round = 0; round <= rounds && rc == RT_OK; ++round) {
     const int nh = (int)list.size() - n_light;
-    unsigned* d_probe = nullptr;
-    if (!hip_ok(hipMalloc((void**)&d_probe, sizeof(unsigned) * 4 * (size_t)nh), "hipMalloc (split probe)")) { rc = RT_ERR_HIP; break; }
+    if ((size_t)nh > probe_cap) {
+      if (d_probe) (void)hipFree(d_probe);
+      d_probe = nullptr;
+      probe_cap = (size_t)nh * 2 + 64;
+      if (!hip_ok(hipMalloc((void**)&d_probe, sizeof(unsigned) * 4 * probe_cap), "hipMalloc (split probe)")) { rc = RT_ERR_HIP; break; }
+    }
     std::vector<unsigned> cyc((size_t)nh * 4, 0u);
     float ms = 1e30f;
     hipError_t e = hipMemsetAsync(d_probe, 0, sizeof(unsigned) * 4 * (size_t)nh, s);
@@ -1825,7 +1835,6 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     }
     if (e == hipSuccess) e = hipMemcpyAsync(cyc.data(), d_probe, sizeof(unsigned) * cyc.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_probe);
     if (!hip_ok(e, "split refinement probe")) { rc = RT_ERR_HIP; break; }
     std::vector<unsigned> cost((size_t)nh);
     unsigned long long total = 0;
@@ -1933,6 +1942,8 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     }
   }
   if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
+  if (d_probe) (void)hipFree(d_probe);
+  plan->refining = false;
   plan->part_cache.clear();
   plan->tile_tris.clear();
   plan->tile_tris.shrink_to_fit();
