@@ -1229,6 +1229,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   a.slist_lds = 0;
   n_blocks = n_tiles;
   double x0, y0, x1, y1;
+  if (n_tiles > RT_TILE_MASK) return RT_OK; /* an entry of a tile order has 22 bits for the tile: larger launches go in raster order */
   if (masked_world(bvh) && cur->light_per_block > 1) {
     const int mrc = plan_masked_world(p, rows, reflect, s, a, n_blocks);
     if (mrc != RT_ERR_INVALID) return mrc; /* RT_ERR_INVALID: not this way after all */
