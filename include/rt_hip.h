@@ -199,7 +199,13 @@ enum {
    * launch is planned for throughput: no tile is split over several
    * workgroups to shorten a lone frame's slowest wave.  Images are the same
    * either way. */
-  RT_RENDER_FRAMES_OVERLAP = 1
+  RT_RENDER_FRAMES_OVERLAP = 1,
+  /* Render with the tile plan as it stands; never measure.  A launch that walks a BVH is as long as its slowest
+   * wave, so the library refines its tile plan by measurement (rt_hip_tune below): dozens of timed launches,
+   * milliseconds, which pay off over a run of frames and cost a one-frame caller - the reference's main(): one
+   * render(), one canvas.ppm, RayTracer.c:7236-7251 - more than the frame itself.  Such a caller sets this bit.
+   * Images are the same either way. */
+  RT_RENDER_NO_TUNE = 2
 };
 
 typedef struct rt_stats {
@@ -276,10 +282,33 @@ int rt_hip_render(const rt_render_params* params, uint8_t* rgb_out, rt_stats* st
 
 /* Same, but rgb_out_device is device memory of the current device and the
  * kernel is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
- * library's own stream).  Nothing is copied to the host and the call does not
- * wait for the kernel unless stats != NULL. */
+ * library's own stream).  Nothing is copied to the host.
+ * stats == NULL: the call only enqueues.  It allocates nothing, creates no
+ * event and waits for nothing, so it may be issued on a stream that is being
+ * captured into a HIP graph.  It uses the tile plan that exists for these
+ * parameters - the one rt_hip_upload_scene makes for a whole frame with
+ * RT_ACCEL_AUTO, or one left by rt_hip_tune or by a synchronous call (rt_hip_render,
+ * or this one with stats) with the same band layout, kernel choice and
+ * RT_RENDER_FRAMES_OVERLAP bit; the library keeps the four most recent.  With no
+ * plan at hand the tiles are launched in raster order: the same image, a
+ * longer launch.
+ * stats != NULL: waits for the kernel; plans, and unless RT_RENDER_NO_TUNE is
+ * set tunes, as rt_hip_render does. */
 int rt_hip_render_device(const rt_render_params* params, void* rgb_out_device, void* stream,
                          rt_stats* stats);
+
+/* Make and tune the tile plan for `params` ahead of time, so that the frames
+ * that follow only enqueue.  Planning sorts the image's 16 x 16 tiles by what
+ * they hold (host work plus one upload).  Tuning applies to launches that walk a
+ * BVH with few enough mesh tiles to be resident at once: such a launch lasts as
+ * long as its slowest wave, so every wave's cycle count is measured, the tiles
+ * with the slowest waves are split over several workgroups, and the shortest
+ * of up to ten candidate orders is kept (7-10 ms for a 1080p frame of 30-100
+ * us; lighthouse 1080p 41 -> 31 us).  Synchronous; renders into a library-owned
+ * image.  The reference has no counterpart (its render(), RayTracer.c:1574, is a
+ * serial loop with nothing to schedule).  RT_OK also when there is nothing to
+ * tune for these parameters. */
+int rt_hip_tune(const rt_render_params* params);
 
 /* The colours before quantisation: what write_pixel() stores into `canvas`
  * (RayTracer.c:255-259), as 3 doubles per pixel, row-major (y outer).  Host
@@ -315,8 +344,11 @@ int rt_hip_ppm_last_length(size_t* bytes_out);
  * text is stored to *length_device (device memory, 8-byte aligned) by the
  * kernel; the call never waits.  Same bytes as rt_hip_format_ppm_device.
  * All calls on one GPU share the array: calls on different streams are
- * ordered one after the other by the library; calls from different host
- * threads at once would race. */
+ * ordered one after the other by the library (the stream of the previous call
+ * must still exist when the next call is made); calls from different host
+ * threads at once would race.  On a stream that is being captured the two
+ * kernels are recorded without any such ordering: the caller orders the
+ * graph's launches against every other use of this entry point on the GPU. */
 int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int height, void* text_device,
                                      size_t capacity, unsigned long long* length_device, void* stream);
 
@@ -338,6 +370,12 @@ int rt_hip_render_ppm(const rt_render_params* params, char* text_host, size_t ca
  * round-robin bands, and the bands come together on device 0 in ONE exchange step over xGMI (a grouped RCCL
  * send/recv: every device sends its rows straight to device 0).  RCCL is loaded (dlopen) by rt_hip_multi_init; a
  * one-GPU host never touches it.  The image does not depend on the number of devices. */
+
+/* Below this many samples per frame (pixels x spp_grid^2) several GPUs do not pay: a frame of 2 M samples is one
+ * launch of 13-30 us, which already sits at the latency of a single wave, while the gather over xGMI and its RCCL
+ * launches cost tens of microseconds; at 50 M samples a GPU works for a millisecond or more and N devices approach
+ * N x (8K x 16 samples: 530 M).  Hosts use the group only when asked to, and never below this. */
+#define RT_MULTI_GPU_MIN_SAMPLES 50000000ll
 
 /* HIP devices visible to the process (0 if there is none or the runtime fails). */
 int rt_hip_device_count(void);

@@ -23,6 +23,7 @@ RT_ACCEL_BVH = 2
 RT_ACCEL_REFERENCE = 3
 
 RT_RENDER_FRAMES_OVERLAP = 1
+RT_RENDER_NO_TUNE = 2
 
 
 class Material(C.Structure):
@@ -227,6 +228,7 @@ def hip_lib():
         L.rt_hip_render.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_device.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.rt_hip_render_f64.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+        L.rt_hip_tune.argtypes = [C.POINTER(RenderParams)]
         L.rt_hip_multi_init.argtypes = [C.c_int]
         L.rt_hip_multi_upload_scene.argtypes = [C.POINTER(Scene)]
         L.rt_hip_render_multi.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
@@ -265,6 +267,7 @@ HIP_EXPORTS = [
     "rt_hip_render",
     "rt_hip_render_device",
     "rt_hip_render_f64",
+    "rt_hip_tune",
     "rt_hip_ppm_capacity",
     "rt_hip_format_ppm_device",
     "rt_hip_ppm_last_length",

@@ -1105,13 +1105,14 @@ bool masked_world(bool bvh) {
   return cur->tile_plan && cur->tile_masks && cur->sphere_masks && !bvh && ns >= 1 && ns <= 64 && nt <= 64 && !cur->sph_world.empty() &&
          !cur->sph_xy.empty() && (nt == 0 || (!cur->tri_xy.empty() && !cur->tri_world.empty()));
 }
-int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStream_t s, RenderArgs& a, int& n_blocks) {
+int plan_masked_world(const rt_render_params* p, int rows, bool reflect, bool may_plan, hipStream_t s, RenderArgs& a, int& n_blocks) {
   const int W = cur->scene.hsize, ns = cur->scene.n_spheres, nt = cur->scene.n_tris;
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const long long key[6] = {(long long)cur->scene_serial, rows, p->n_ranks > 1 ? p->band_rows : 1, p->n_ranks, p->rank,
                             (1ll << 20) + cur->light_per_block * 8 + (reflect ? 4 : 0)};
   bool fresh = false;
   Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh && !may_plan) return RT_ERR_INVALID; /* the caller launches in raster order, without masks */
   if (fresh) {
     std::vector<int> y_lo((size_t)tiles_y, 1 << 30), y_hi((size_t)tiles_y, -1);
     for (int ty = 0; ty < tiles_y; ++ty)
@@ -1211,8 +1212,11 @@ int plan_masked_world(const rt_render_params* p, int rows, bool reflect, hipStre
 }
 
 /* Tile order for a launch: tiles that can see the mesh first (one per workgroup), the rest after (several
- * per workgroup).  Kept until the scene or the band layout changes. */
-int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool overlap, hipStream_t s, RenderArgs& a, int& n_blocks) {
+ * per workgroup).  Kept until the scene or the band layout changes.
+ * may_plan == false (an entry point that has promised only to enqueue): a plan that exists is used, a plan that
+ * does not is not made (making one allocates, copies and waits for the copy); the launch then takes its tiles in
+ * raster order, which changes how long it runs and nothing else. */
+int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool overlap, bool may_plan, hipStream_t s, RenderArgs& a, int& n_blocks) {
   const int W = cur->scene.hsize;
   const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
   const int n_tiles = tiles_x * tiles_y;
@@ -1231,7 +1235,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
   double x0, y0, x1, y1;
   if (n_tiles > RT_TILE_MASK) return RT_OK; /* an entry of a tile order has 22 bits for the tile: larger launches go in raster order */
   if (masked_world(bvh) && cur->light_per_block > 1) {
-    const int mrc = plan_masked_world(p, rows, reflect, s, a, n_blocks);
+    const int mrc = plan_masked_world(p, rows, reflect, may_plan, s, a, n_blocks);
     if (mrc != RT_ERR_INVALID) return mrc; /* RT_ERR_INVALID: not this way after all */
     cur->launch_tile_list = nullptr;
     cur->launch_tile_mask = nullptr;
@@ -1248,6 +1252,7 @@ int plan_tiles(const rt_render_params* p, int rows, bool bvh, bool reflect, bool
                             cur->light_per_block * 8 + (bvh ? 1 : 0) + (overlap ? 2 : 0) + (reflect ? 4 : 0)};
   bool fresh = false;
   Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh && !may_plan) return RT_OK;
   if (fresh) {
     std::vector<int32_t> heavy, light;
     /* image rows covered by every tile row (bands make packed rows non-contiguous in y) */
@@ -1686,7 +1691,7 @@ void launch_general(bool count, dim3 grid, hipStream_t s, const RenderArgs& a, u
  * four pixels of every tile and counts their rays, and the tiles then start, block by block, in descending order
  * of that count.
  * Kept in the same plan cache as plan_tiles' lists, keyed by scene, band layout and depth. */
-int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const RenderArgs& a) {
+int plan_general_tiles(const rt_render_params* p, int rows, bool may_plan, hipStream_t s, const RenderArgs& a) {
   cur->launch_tile_list = nullptr;
   if (!cur->tile_plan) return RT_OK;
   const int tiles_x = (cur->scene.hsize + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
@@ -1697,6 +1702,7 @@ int plan_general_tiles(const rt_render_params* p, int rows, hipStream_t s, const
                             -2 - (long long)p->max_depth - ((long long)(p->accel == RT_ACCEL_REFERENCE) << 20)};
   bool fresh = false;
   Context::TilePlan* const plan = find_plan(key, fresh);
+  if (fresh && !may_plan) return RT_OK; /* raster order */
   if (fresh) {
     int32_t* d_cost = nullptr;
     HIP_TRY(hipMalloc((void**)&d_cost, sizeof(int32_t) * (size_t)n_tiles));
@@ -1777,14 +1783,14 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   long long key[6];
   memcpy(key, plan->key, sizeof key);
   hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
+  if (!hip_ok(hipEventCreate(&e0), "hipEventCreate")) { plan->refining = false; return RT_ERR_HIP; }
   if (!hip_ok(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); plan->refining = false; return RT_ERR_HIP; }
   float best_ms = 1e30f;
   std::vector<unsigned> best_cost; /* the slowest wave of every mesh entry of best_list, as measured with that list */
   bool current_is_best = true;
   int stale = 0; /* rounds in a row that did not win */
   int rc = RT_OK;
-  const bool with_lists = plan->list_forms != 0 && !plan->tile_tris.empty();
+  bool with_lists = plan->list_forms != 0 && !plan->tile_tris.empty();
   auto adopt = [&](const std::vector<int32_t>& l) {
     std::vector<int32_t> full;
     if (with_lists) { /* the entries changed: so do the words behind them that say where each entry's triangle list lies */
@@ -1907,6 +1913,9 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     rc = adopt(list);
     current_is_best = false;
   }
+  /* a candidate whose triangle lists would not fit (RT_ERR_INVALID from adopt) ends the search; the best list so
+   * far is what the plan keeps */
+  if (rc == RT_ERR_INVALID) rc = RT_OK;
   /* The list that won was put in order by what the round before it had measured, with estimates for the entries it
    * had just split.  Its own measurement is at hand: the same entries, longest first by that, are tried as well
    * (an entry that was guessed too cheap starts in a later round of workgroups, and the frame then waits for it). */
@@ -1919,7 +1928,10 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
     resorted.reserve(best_list.size());
     for (int32_t i : order) resorted.push_back(best_list[(size_t)i]);
     resorted.insert(resorted.end(), best_list.begin() + (long)nh, best_list.end());
-    if (resorted != best_list && (rc = adopt(resorted)) == RT_OK) {
+    if (resorted != best_list && (rc = adopt(resorted)) == RT_ERR_INVALID) {
+      rc = RT_OK;
+      current_is_best = false;
+    } else if (resorted != best_list && rc == RT_OK) {
       float ms = 1e30f;
       hipError_t e = hipSuccess;
       for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) {
@@ -1942,7 +1954,15 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
       }
     }
   }
-  if (rc == RT_OK && !current_is_best) rc = adopt(best_list);
+  if (rc == RT_OK && !current_is_best) {
+    rc = adopt(best_list);
+    if (rc == RT_ERR_INVALID) { /* cannot happen for a list that was adopted before; if it does: the entries without lists */
+      with_lists = false;
+      plan->list_forms = 0;
+      plan->list_total = 0;
+      rc = adopt(best_list);
+    }
+  }
   if (d_probe) (void)hipFree(d_probe);
   plan->refining = false;
   plan->part_cache.clear();
@@ -1956,10 +1976,14 @@ int refine_split(Context::TilePlan* plan, bool bvh, bool reflect, hipStream_t s,
   return rc;
 }
 
-/* Enqueue one render of the current context's scene on `s` and return at once.  timed: record the context's
- * event pair around the kernel; count: the counting build, counters zeroed first. */
+/* Enqueue one render of the current context's scene on `s`.  timed: record the context's event pair around the
+ * kernel; count: the counting build, counters zeroed first.
+ * may_plan: a tile order that does not exist yet for these parameters may be made (allocates, copies, waits for
+ * the copy); may_tune: a plan whose split has not been measured yet may be refined now (refine_split: dozens of
+ * timed launches into d_rgb, milliseconds).  With both false the call only enqueues: no allocation, no event is
+ * created, nothing is waited for, so it is legal on a stream that is being captured. */
 int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, bool timed, bool count,
-                   Enqueued* out) {
+                   bool may_plan, bool may_tune, Enqueued* out) {
   const int W = cur->scene.hsize, H = cur->scene.vsize;
   const int rows = rt_hip_rank_rows(H, p->band_rows, p->n_ranks, p->rank);
   RenderArgs a;
@@ -1996,12 +2020,12 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
   a.slist_lds = 0;
       n_blocks = (int)n_tiles;
       bvh = false;
-      const int prc = plan_general_tiles(p, rows, s, a);
+      const int prc = plan_general_tiles(p, rows, may_plan, s, a);
       if (prc != RT_OK) return prc;
     } else {
-      const int prc = plan_tiles(p, rows, bvh, reflect, overlap, s, a, n_blocks);
+      const int prc = plan_tiles(p, rows, bvh, reflect, overlap, may_plan, s, a, n_blocks);
       if (prc != RT_OK) return prc;
-      if (bvh && !count && cur->launch_plan && cur->launch_plan->refine_left > 0) {
+      if (bvh && !count && may_tune && !(p->flags & RT_RENDER_NO_TUNE) && cur->launch_plan && cur->launch_plan->refine_left > 0) {
         const int rrc = refine_split(cur->launch_plan, bvh, reflect, s, a, d_rgb, d_canvas, n_blocks);
         if (rrc != RT_OK) return rrc;
       }
@@ -2050,10 +2074,11 @@ int render_collect(const Enqueued& e, hipStream_t s, rt_stats* stats) {
   return RT_OK;
 }
 
-/* enqueue one render on `s`; waits and fills stats only when stats != NULL */
-int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats) {
+/* enqueue one render on `s`; waits and fills stats only when stats != NULL.  synchronous: the entry point waits
+ * for the frame anyway, so it may plan and tune first */
+int render_common(const rt_render_params* p, unsigned char* d_rgb, double* d_canvas, hipStream_t s, rt_stats* stats, bool synchronous) {
   Enqueued e;
-  const int rc = render_enqueue(p, d_rgb, d_canvas, s, stats != nullptr, p->count_rays != 0 && stats != nullptr, &e);
+  const int rc = render_enqueue(p, d_rgb, d_canvas, s, stats != nullptr, p->count_rays != 0 && stats != nullptr, synchronous, synchronous, &e);
   if (rc != RT_OK || !stats) return rc;
   return render_collect(e, s, stats);
 }
@@ -2086,7 +2111,7 @@ int warm_launch() {
   const bool bvh = cur->scene.n_bvh_nodes > 0 && cur->scene.n_tris >= 32;
   int n_blocks = 0;
   a.rows = H;
-  const int prc = cur->general ? plan_general_tiles(&p, H, cur->stream, a) : plan_tiles(&p, H, bvh, cur->reflective, false, cur->stream, a, n_blocks);
+  const int prc = cur->general ? plan_general_tiles(&p, H, true, cur->stream, a) : plan_tiles(&p, H, bvh, cur->reflective, false, true, cur->stream, a, n_blocks);
   if (prc != RT_OK) return prc;
   a.rows = 0; /* ... but the launch itself renders nothing */
   a.n_heavy = 0;
@@ -2748,8 +2773,11 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   /* A mesh this large without a tree would be walked exhaustively by every ray (seconds per frame): build one
    * here.  A tree that turns out too deep for the walk leaves the scene as it is. */
   if (!use_bvh && !cur->bvh_single_leaf && nt >= kAutoDeviceBvhTris) {
+    /* Not fatal: a tree too deep for the walk (RT_ERR_TOO_LARGE), or no librt_hip_sort.so beside this library
+     * (RT_ERR_UNSUPPORTED; rt_hip_last_error says so): the scene stays, rendered by the exhaustive loop.  Only the
+     * explicit rt_hip_build_bvh_device call reports those. */
     const int rc = rt_hip_build_bvh_device(4, nullptr);
-    if (rc != RT_OK && rc != RT_ERR_TOO_LARGE) return rc;
+    if (rc != RT_OK && rc != RT_ERR_TOO_LARGE && rc != RT_ERR_UNSUPPORTED) return rc;
   }
   return warm_launch();
 }
@@ -2967,9 +2995,23 @@ int rt_hip_format_ppm_device_noalloc(const void* rgb_device, int width, int heig
   unsigned* const group_len = cur->ppm_scratch_ptr + (kNoAllocMaxChunks + 1);
   /* the scratch is one per GPU: a call on another stream than the last one starts after that one has finished.
    * Nothing in it has to start at zero: the length pass writes every entry the write pass reads. */
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+  if (capturing != hipStreamCaptureStatusNone) {
+    /* Under capture nothing outside the capture may be waited for (an event recorded on another stream would
+     * invalidate it), and when the graph will run is not known here: the two kernels are recorded as they are, and
+     * the caller orders the graph's launches against every other user of this GPU's scratch. */
+    return ppm_enqueue(rgb_device, width, height, text_device, chunk_len, group_len, length_device, s);
+  }
   if (cur->noalloc_pending && cur->noalloc_stream != s) {
-    HIP_TRY(hipEventRecord(cur->ppm_ev, cur->noalloc_stream));
-    HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
+    /* the earlier stream must still exist (see the header); once it has drained there is nothing to order */
+    const hipError_t busy = hipStreamQuery(cur->noalloc_stream);
+    (void)hipGetLastError(); /* "not ready" is an answer, not a failure */
+    if (busy == hipErrorNotReady) {
+      HIP_TRY(hipEventRecord(cur->ppm_ev, cur->noalloc_stream));
+      HIP_TRY(hipStreamWaitEvent(s, cur->ppm_ev, 0));
+    }
+    cur->noalloc_pending = false;
   }
   const int erc = ppm_enqueue(rgb_device, width, height, text_device, chunk_len, group_len, length_device, s);
   if (erc != RT_OK) return erc;
@@ -3013,7 +3055,7 @@ int rt_hip_render_ppm(const rt_render_params* p, char* text_host, size_t capacit
     HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes ? bytes : 16));
     cur->d_rgb_bytes = bytes;
   }
-  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats);
+  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats, true);
   if (rc != RT_OK) return rc;
   return rt_hip_format_ppm(cur->d_rgb, cur->scene.hsize, cur->scene.vsize, text_host, capacity, bytes_out);
 }
@@ -3064,7 +3106,7 @@ int rt_hip_render_ppm_submit(const rt_render_params* p, int slot) {
   hipEvent_t keep0 = cur->ev0, keep1 = cur->ev1;
   cur->ev0 = q.k0;
   cur->ev1 = q.k1;
-  rc = render_enqueue(p, q.d_rgb, nullptr, s, true, p->count_rays != 0, &q.enq);
+  rc = render_enqueue(p, q.d_rgb, nullptr, s, true, p->count_rays != 0, true, false, &q.enq); /* plans, never tunes: rt_hip_tune does */
   cur->ev0 = keep0;
   cur->ev1 = keep1;
   if (rc != RT_OK) return rc;
@@ -3130,7 +3172,31 @@ int rt_hip_render_device(const rt_render_params* p, void* rgb_out_device, void* 
   if (rc != RT_OK) return rc;
   if (!rgb_out_device) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : cur->stream;
-  return render_common(p, (unsigned char*)rgb_out_device, nullptr, s, stats);
+  return render_common(p, (unsigned char*)rgb_out_device, nullptr, s, stats, stats != nullptr);
+}
+
+int rt_hip_tune(const rt_render_params* p) {
+  int rc = check_params(p);
+  if (rc != RT_OK) return rc;
+  const int rows = rt_hip_rank_rows(cur->scene.vsize, p->band_rows, p->n_ranks, p->rank);
+  const size_t bytes = (size_t)rows * cur->scene.hsize * 3;
+  if (bytes > cur->d_rgb_bytes) {
+    HIP_TRY(hipStreamSynchronize(cur->stream));
+    if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+    cur->d_rgb = nullptr;
+    cur->d_rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes));
+    cur->d_rgb_bytes = bytes;
+  }
+  rt_render_params q = *p;
+  q.count_rays = 0;
+  q.flags &= ~(int32_t)RT_RENDER_NO_TUNE;
+  Enqueued e;
+  /* the measured launches (and one last frame) go into the library's own image */
+  rc = render_enqueue(&q, cur->d_rgb, nullptr, cur->stream, false, false, true, true, &e);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(cur->stream));
+  return RT_OK;
 }
 
 int rt_hip_render(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) {
@@ -3146,7 +3212,7 @@ int rt_hip_render(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) 
     HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes));
     cur->d_rgb_bytes = bytes;
   }
-  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats);
+  rc = render_common(p, cur->d_rgb, nullptr, cur->stream, stats, true);
   if (rc != RT_OK) return rc;
   if (bytes) HIP_TRY(hipMemcpyAsync(rgb_out, cur->d_rgb, bytes, hipMemcpyDeviceToHost, cur->stream));
   HIP_TRY(hipStreamSynchronize(cur->stream));
@@ -3166,7 +3232,7 @@ int rt_hip_render_f64(const rt_render_params* p, double* canvas_out, rt_stats* s
     HIP_TRY(hipMalloc((void**)&cur->d_canvas, bytes));
     cur->d_canvas_bytes = bytes;
   }
-  rc = render_common(p, nullptr, cur->d_canvas, cur->stream, stats);
+  rc = render_common(p, nullptr, cur->d_canvas, cur->stream, stats, true);
   if (rc != RT_OK) return rc;
   if (bytes) HIP_TRY(hipMemcpyAsync(canvas_out, cur->d_canvas, bytes, hipMemcpyDeviceToHost, cur->stream));
   HIP_TRY(hipStreamSynchronize(cur->stream));
@@ -3282,7 +3348,8 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
       }
       target = cur->d_rgb;
     }
-    if ((rc = render_enqueue(&q, target, nullptr, cur->stream, want, count, &enq[d])) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+    /* plans, never tunes here: no device waits for another's measurements (they are made after the frame, below) */
+    if ((rc = render_enqueue(&q, target, nullptr, cur->stream, want, count, true, false, &enq[d])) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
   }
   /* one exchange step: every other device sends its rows to device 0 over its own link (a grouped send/recv:
    * the gather has a fixed root and unequal parts, which no single RCCL collective expresses) */
@@ -3291,12 +3358,16 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
   if (want) HIP_TRY(hipEventRecord(g_multi_t0, s0));
   if (n > 1) {
     RCCL_TRY(g_rccl.GroupStart());
-    for (int d = 1; d < n; ++d) {
+    bool group_ok = true; /* a group that was opened is closed whatever happens inside it */
+    for (int d = 1; d < n && group_ok; ++d) {
       if (bytes[d] == 0) continue;
-      RCCL_TRY(g_rccl.Send(g_ctx[d].d_rgb, bytes[d], ncclUint8, 0, g_comms[d], g_ctx[d].stream));
-      RCCL_TRY(g_rccl.Recv(g_gather + offset[d], bytes[d], ncclUint8, d, g_comms[0], s0));
+      group_ok = rccl_ok(g_rccl.Send(g_ctx[d].d_rgb, bytes[d], ncclUint8, 0, g_comms[d], g_ctx[d].stream), "ncclSend") &&
+                 rccl_ok(g_rccl.Recv(g_gather + offset[d], bytes[d], ncclUint8, d, g_comms[0], s0), "ncclRecv");
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t ended = g_rccl.GroupEnd();
+    (void)rt_hip_set_device(0);
+    if (!group_ok) return RT_ERR_HIP;
+    if (!rccl_ok(ended, "ncclGroupEnd")) return RT_ERR_HIP;
   }
   if ((rc = rt_hip_place_bands_device(g_gather, g_final, W, H, band, n, s0)) != RT_OK) return rc;
   if (want) HIP_TRY(hipEventRecord(g_multi_t1, s0));
@@ -3322,6 +3393,17 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
     HIP_TRY(hipEventElapsedTime(&ms, g_multi_t0, g_multi_t1));
     sum.exchange_ms = ms;
     *stats = sum;
+  }
+  /* the frame is out; a caller that will render more (no RT_RENDER_NO_TUNE) gets every device's plan tuned now */
+  if (!(p->flags & RT_RENDER_NO_TUNE) && !count) {
+    for (int d = 0; d < n; ++d) {
+      if (rt_hip_set_device(d) != RT_OK) break;
+      q.rank = d;
+      bool pending = false;
+      for (const Context::TilePlan& t : cur->plans) pending = pending || (t.refine_left > 0 && t.key[0] == (long long)cur->scene_serial);
+      if (pending && (rc = rt_hip_tune(&q)) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+    }
+    if ((rc = rt_hip_set_device(0)) != RT_OK) return rc;
   }
   return RT_OK;
 }

@@ -92,6 +92,32 @@ __device__ __forceinline__ d3 reflect3(d3 in, d3 n) {                           
   return sub3(in, scale3(two_n, d));
 }
 
+/* pow(x, y) as lighting() and schlick() call it (:1310 with y = material.shininess, 200 in every stock material
+ * (:710); :1480 with y = 5).  pow() is the one operation on the path whose last bits already differ between
+ * the reference's libm and any device library, and its device expansion is the largest block of instructions
+ * of a shaded point (~150 against ~60 for everything else lighting() does).  For an integer-valued exponent
+ * of at most 1024 the power is formed by squaring and multiplying instead: at most 10 squarings and 10
+ * products, each rounded once, so the result is within y * 2^-53 relative of the exact power (2.3e-14 for
+ * y = 200) - the same order as the difference between two correctly working pow() implementations after the
+ * reference's own rounding of x, and four orders of magnitude inside what can move an 8-bit colour value.
+ * Any other exponent goes to the library routine. */
+#ifndef RT_POW_BY_SQUARING
+#define RT_POW_BY_SQUARING 1 /* 0: always the library routine (A/B builds) */
+#endif
+__device__ __forceinline__ double rt_pow(double x, double y) {
+  const int e = (int)y;
+  if (RT_POW_BY_SQUARING && y >= 0.0 && y <= 1024.0 && (double)e == y) {
+    double r = (e & 1) ? x : 1.0, b = x;
+#pragma unroll 1
+    for (int k = e >> 1; k != 0; k >>= 1) {
+      b = b * b;
+      if (k & 1) r = r * b;
+    }
+    return r;
+  }
+  return pow(x, y);
+}
+
 /* rows 0..2 of a row-major 4x4 whose bottom row is 0 0 0 1 (mat4x4_mul_tuple, :419) */
 __device__ __forceinline__ d3 xform_point(const double* __restrict__ m, d3 p) { /* w == 1: 1 * m[3] == m[3] */
   return mk3(((p.x * m[0] + p.y * m[1]) + p.z * m[2]) + m[3], ((p.x * m[4] + p.y * m[5]) + p.z * m[6]) + m[7],

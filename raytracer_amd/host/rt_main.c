@@ -4,7 +4,7 @@
  *
  *   raytracer_hip [scene] [--size W H] [--obj mesh.obj | --tris-f32 file] [--out canvas.ppm]
  *                 [--spp-grid G] [--tri-reflective K] [--sph-reflective K] [--brute | --bvh] [--device N]
- *                 [--host-ppm] [--reference-list] [--device-bvh] [--gpus N] [--frames K] [--json] [--no-count]
+ *                 [--host-ppm] [--reference-list] [--device-bvh] [--gpus N] [--frames K] [--json] [--no-count] [--tune]
  *
  * scene: lighthouse (default, like the reference's main), cube, spheres, cube_spheres, refraction,
  * world_with_plane, dual_spheres.
@@ -13,8 +13,11 @@
  * --host-ppm asks for the C writer rt_write_ppm; both emit the bytes of write_canvas_to_file (:1333).
  * --device-bvh skips the host's SAH tree and builds one on the GPU (rt_hip_build_bvh_device).
  * --gpus N (0 = every visible device) renders the frame on N GPUs of this process (rt_hip_render_multi: row bands,
- * one RCCL gather to device 0); --frames K repeats the render K times and reports the mean wall time per frame;
- * --json prints one line of figures for scripts.
+ * one RCCL gather to device 0; a frame of fewer than RT_MULTI_GPU_MIN_SAMPLES samples is rendered on one device unless
+ * N is given explicitly as 2 or more); --frames K repeats the render K times and reports the mean wall time per frame;
+ * --json prints one line of figures for scripts.  A single frame is rendered with the tile plan as it stands
+ * (RT_RENDER_NO_TUNE: like the reference, one render() per process); --frames K > 1 or --tune tunes the plan first
+ * (rt_hip_tune) and reports what that took.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
   const char* obj = "lighthouse.obj";
   const char* tris_f32 = NULL;
   const char* out = "canvas.ppm";
-  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0, gpus = -1, frames = 1, json = 0, count = 1; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
+  int W = 300, H = 300, G = 1, device = 0, accel = RT_ACCEL_AUTO, host_ppm = 0, device_bvh = 0, gpus = -1, frames = 1, json = 0, count = 1, tune = 0; /* HORIZONTAL_SIZE x VERTICAL_SIZE, :42-43 */
   double tri_refl = 0.0, sph_refl = 0.0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) { W = atoi(argv[++i]); H = atoi(argv[++i]); }
@@ -59,6 +62,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--json")) json = 1;
+    else if (!strcmp(argv[i], "--tune")) tune = 1;
     else if (!strcmp(argv[i], "--no-count")) count = 0; /* the production kernel from the first call on (no ray counters) */
     else if (argv[i][0] != '-') scene = argv[i];
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
@@ -89,8 +93,10 @@ int main(int argc, char** argv) {
   rt_scene s;
   if ((rc = rt_scene_finish(b, device_bvh ? 0 : 4, &s)) != RT_OK) return fail("rt_scene_finish", rc);
 
-  const int multi = gpus >= 0;
+  /* --gpus 0: every visible device if the frame is worth it, else one */
+  const int multi = gpus >= 2 || gpus == 1 || (gpus == 0 && (long long)W * H * G * G >= RT_MULTI_GPU_MIN_SAMPLES && rt_hip_device_count() > 1);
   if (frames < 1) frames = 1;
+  if (frames > 1) tune = 1;
   double t_init = now_s(), init_ms = 0.0, upload_ms = 0.0;
   if (multi) {
     host_ppm = 1; /* the gathered image comes back as 8-bit rows; the C writer emits the file */
@@ -113,8 +119,15 @@ int main(int argc, char** argv) {
   uint8_t* buf = malloc(cap ? cap : 1); /* the 8-bit image, or the text of the file */
   if (!buf) return 1;
   size_t text_len = 0;
-  rt_render_params p = {5 /* RECURSION_DEPTH */, G, accel, count, 1, 1, 0, 0};
+  rt_render_params p = {5 /* RECURSION_DEPTH */, G, accel, count, 1, 1, 0, tune ? 0 : RT_RENDER_NO_TUNE};
   rt_stats st;
+  double tune_ms = 0.0;
+  if (tune && !multi) {
+    const double tt = now_s();
+    if ((rc = rt_hip_tune(&p)) != RT_OK) return fail("rt_hip_tune", rc);
+    tune_ms = (now_s() - tt) * 1e3;
+    printf("tile plan tuned in %.3f ms\n", tune_ms);
+  }
   printf("Starting Render Process\n");
   double t0 = now_s();
   if (multi) {
@@ -153,9 +166,9 @@ int main(int argc, char** argv) {
   }
   if (json)
     printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_grid\": %d, \"gpus\": %d, \"rays\": %llu, "
-           "\"init_ms\": %.3f, \"upload_ms\": %.3f, \"first_call_ms\": %.4f, \"first_call_kernel_ms\": %.4f, \"frames\": %d, "
+           "\"init_ms\": %.3f, \"upload_ms\": %.3f, \"tune_ms\": %.3f, \"first_call_ms\": %.4f, \"first_call_kernel_ms\": %.4f, \"frames\": %d, "
            "\"ms_per_frame\": %.5f, \"kernel_ms\": %.5f, \"exchange_ms\": %.5f}\n",
-           scene, W, H, G, multi ? rt_hip_multi_devices() : 1, rays, init_ms, upload_ms, dt * 1e3, st.kernel_ms, frames, per_frame_ms,
+           scene, W, H, G, multi ? rt_hip_multi_devices() : 1, rays, init_ms, upload_ms, tune_ms, dt * 1e3, st.kernel_ms, frames, per_frame_ms,
            kernel_ms, exchange_ms);
   printf("Writing Canvas To File\n");
   if (host_ppm) {

@@ -75,36 +75,49 @@ int rt_binding_flatten(camera* c, world* w, rt_scene_builder** builder, rt_scene
   return rc < 0 ? rc : RT_OK;
 }
 
-/* returns RT_OK or a negative rt_status; on an error the caller keeps its CPU loop */
+/* The 8-bit rows of a gathered frame into canvas[][]: the centre of each 8-bit step, which color_convert
+ * (RayTracer.c:1322) maps back to the same byte, so write_canvas_to_file() emits the same file. */
+static void rt_binding_store_rgb(const uint8_t* rgb) {
+  for (int y = 0; y < VERTICAL_SIZE; ++y)
+    for (int x = 0; x < HORIZONTAL_SIZE; ++x) {
+      const uint8_t* px = rgb + ((size_t)y * HORIZONTAL_SIZE + x) * 3;
+      tuple col = {(px[0] + 0.5) / 255.0, (px[1] + 0.5) / 255.0, (px[2] + 0.5) / 255.0, 1.0};
+      write_pixel(x, y, col);
+    }
+}
+
+/* returns RT_OK or a negative rt_status; on an error the caller keeps its CPU loop.
+ * One device is the default: the reference's use is one process and one render() (RayTracer.c:7236-7251), and a
+ * frame of HORIZONTAL_SIZE x VERTICAL_SIZE pixels is far below what several GPUs pay for
+ * (RT_MULTI_GPU_MIN_SAMPLES).  RT_HIP_GPUS=n (n > 1) in the environment asks for n devices; if that path fails
+ * for any reason (no RCCL, fewer devices, a failing exchange) the frame is rendered on device 0 after all.
+ * One frame per process: the plan is not tuned (RT_RENDER_NO_TUNE). */
 int rt_render_hip(camera* c, world* w) {
   if ((int)c->hsize != HORIZONTAL_SIZE || (int)c->vsize != VERTICAL_SIZE) return RT_ERR_UNSUPPORTED; /* canvas[][] is fixed */
   rt_scene_builder* b = NULL;
   rt_scene s;
   int rc = rt_binding_flatten(c, w, &b, &s);
-  if (rc == RT_OK && rt_hip_device_count() > 1) {
-    /* several MI355X: every device renders its row bands, one RCCL gather brings the 8-bit rows to device 0.
-     * canvas[][] then holds the centre of each 8-bit step, which color_convert (RayTracer.c:1322) maps back to
-     * the same byte, so write_canvas_to_file() emits the same file. */
+  if (rc != RT_OK) { rt_scene_destroy(b); return rc; }
+  rt_render_params p = {RECURSION_DEPTH, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, RT_RENDER_NO_TUNE};
+  const char* asked = getenv("RT_HIP_GPUS");
+  const int gpus = asked ? atoi(asked) : 1;
+  if (gpus > 1 && rt_hip_device_count() >= gpus) {
+    /* every device renders its row bands, one RCCL gather brings the 8-bit rows to device 0 */
     static uint8_t rgb[HORIZONTAL_SIZE * VERTICAL_SIZE * 3];
-    rt_render_params p = {RECURSION_DEPTH, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, 0};
-    rc = rt_hip_multi_init(0);
-    if (rc == RT_OK) rc = rt_hip_multi_upload_scene(&s);
-    if (rc == RT_OK) rc = rt_hip_render_multi(&p, rgb, NULL);
-    if (rc == RT_OK)
-      for (int y = 0; y < VERTICAL_SIZE; ++y)
-        for (int x = 0; x < HORIZONTAL_SIZE; ++x) {
-          const uint8_t* px = rgb + ((size_t)y * HORIZONTAL_SIZE + x) * 3;
-          tuple col = {(px[0] + 0.5) / 255.0, (px[1] + 0.5) / 255.0, (px[2] + 0.5) / 255.0, 1.0};
-          write_pixel(x, y, col);
-        }
-    rt_scene_destroy(b);
-    return rc;
+    int mrc = rt_hip_multi_init(gpus);
+    if (mrc == RT_OK) mrc = rt_hip_multi_upload_scene(&s);
+    if (mrc == RT_OK) mrc = rt_hip_render_multi(&p, rgb, NULL);
+    if (mrc == RT_OK) {
+      rt_binding_store_rgb(rgb);
+      rt_scene_destroy(b);
+      return RT_OK;
+    }
+    fprintf(stderr, "rt_render_hip: %d GPUs failed (%s: %s); rendering on one\n", gpus, rt_hip_strerror(mrc), rt_hip_last_error());
   }
-  if (rc == RT_OK) rc = rt_hip_init(0);
+  rc = rt_hip_init(0);
   if (rc == RT_OK) rc = rt_hip_upload_scene(&s);
   if (rc == RT_OK) {
     static double colours[HORIZONTAL_SIZE * VERTICAL_SIZE * 3];
-    rt_render_params p = {RECURSION_DEPTH, 1, RT_ACCEL_AUTO, 0, 1, 1, 0, 0};
     rc = rt_hip_render_f64(&p, colours, NULL);
     if (rc == RT_OK)
       for (int y = 0; y < VERTICAL_SIZE; ++y)

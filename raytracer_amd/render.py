@@ -26,11 +26,14 @@ def _check(rc, what):
 
 
 def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0,
-                flags=0, frames_overlap=False):
+                flags=0, frames_overlap=False, no_tune=False):
     """rt_render_params; frames_overlap=True states that the caller keeps several frames in flight on different
-    streams (RT_RENDER_FRAMES_OVERLAP)."""
+    streams (RT_RENDER_FRAMES_OVERLAP); no_tune=True that the tile plan is to be used as it stands
+    (RT_RENDER_NO_TUNE: a one-frame caller)."""
     if frames_overlap:
         flags |= _ffi.RT_RENDER_FRAMES_OVERLAP
+    if no_tune:
+        flags |= _ffi.RT_RENDER_NO_TUNE
     return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, flags)
 
 
@@ -42,17 +45,20 @@ class HipRenderer:
         _check(self._L.rt_hip_init(int(device)), "rt_hip_init")
         self.device = int(device)
         self._scene = None
+        self._tuned = set()
 
     def upload(self, scene):
         _check(self._L.rt_hip_upload_scene(C.byref(scene)), "rt_hip_upload_scene")
         self._scene = scene  # keeps the host arrays alive; the device copy is independent
         self.width, self.height = scene.camera.hsize, scene.camera.vsize
+        self._tuned = set()
         return self
 
     def build_bvh_device(self, leaf_size=4):
         """Replace the scene's BVH by one built on the GPU; returns (inner nodes, depth, build ms)."""
         info = _ffi.BvhDeviceInfo()
         _check(self._L.rt_hip_build_bvh_device(int(leaf_size), C.byref(info)), "rt_hip_build_bvh_device")
+        self._tuned = set()
         return info.n_nodes, info.depth, info.build_ms
 
     def scene_counts(self):
@@ -80,8 +86,23 @@ class HipRenderer:
         _check(self._L.rt_hip_render_f64(C.byref(p), out.ctypes.data, C.byref(st)), "rt_hip_render_f64")
         return out, st
 
+    def tune(self, params=None, **kw):
+        """Make and tune the tile plan for these parameters now (rt_hip_tune), so that render_device() without
+        stats only enqueues from its first frame on."""
+        p = params or make_params(**kw)
+        _check(self._L.rt_hip_tune(C.byref(p)), "rt_hip_tune")
+        self._tuned.add(self._plan_key(p))
+
+    @staticmethod
+    def _plan_key(p):
+        return (p.max_depth, p.spp_grid, p.accel, p.band_rows, p.n_ranks, p.rank, p.flags & ~_ffi.RT_RENDER_NO_TUNE)
+
     def render_device(self, data_ptr, params, stream=None, stats=None):
-        """Enqueue a render into device memory at `data_ptr` (e.g. a torch uint8 tensor's data_ptr())."""
+        """Enqueue a render into device memory at `data_ptr` (e.g. a torch uint8 tensor's data_ptr()).  Without
+        stats the C call only enqueues and uses the tile plan at hand; this wrapper makes that plan first
+        (tune(), once per scene and parameter set) unless the parameters carry RT_RENDER_NO_TUNE."""
+        if stats is None and not (params.flags & _ffi.RT_RENDER_NO_TUNE) and self._plan_key(params) not in self._tuned:
+            self.tune(params)
         _check(
             self._L.rt_hip_render_device(
                 C.byref(params), C.c_void_p(data_ptr), C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None
