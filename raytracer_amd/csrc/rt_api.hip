@@ -301,6 +301,67 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
   return 1 + (l > r ? l : r);
 }
 
+/* The caller's binary tree as four-wide nodes.  A wide node starts as the two children of a binary node; while it has
+ * fewer than four slots, the inner child with the largest surface area is replaced by its own two children (the
+ * child a ray is most likely to enter is the one worth opening).  Leaves stay as they are.  Boxes are the callers'
+ * padded by `pad` and rounded outwards.  stack_need: the most subtrees a walk can have postponed at once (a step
+ * postpones all but one of the children it enters).  Returns the index of the wide node made for binary node b. */
+struct WideBuild {
+  const rt_bvh_node* nodes;
+  double pad;
+  std::vector<DevBvh4>* out;
+};
+int wide_node(const WideBuild& w, int b, int& stack_need) {
+  const rt_bvh_node* nodes = w.nodes;
+  int slot[4] = {nodes[b].left, nodes[b].right, -1, -1};
+  int k = 2;
+  auto area = [&](int i) {
+    const double dx = (double)nodes[i].hi[0] - nodes[i].lo[0], dy = (double)nodes[i].hi[1] - nodes[i].lo[1], dz = (double)nodes[i].hi[2] - nodes[i].lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  while (k < 4) {
+    int open = -1;
+    for (int j = 0; j < k; ++j)
+      if (nodes[slot[j]].right >= 0 && (open < 0 || area(slot[j]) > area(slot[open]))) open = j;
+    if (open < 0) break;
+    const int c = slot[open];
+    slot[open] = nodes[c].left;
+    slot[k++] = nodes[c].right;
+  }
+  const int me = (int)w.out->size();
+  w.out->push_back(DevBvh4{});
+  float box[6][4];
+  int32_t ref[4];
+  int deepest = 0;
+  for (int j = 0; j < 4; ++j) {
+    if (j >= k) {
+      for (int c = 0; c < 6; ++c) box[c][j] = NAN;
+      ref[j] = RT_BVH_EMPTY_REF;
+      continue;
+    }
+    const rt_bvh_node& n = nodes[slot[j]];
+    for (int c = 0; c < 3; ++c) {
+      box[c][j] = std::nextafterf((float)((double)n.lo[c] - w.pad), -INFINITY);
+      box[3 + c][j] = std::nextafterf((float)((double)n.hi[c] + w.pad), INFINITY);
+    }
+    if (n.right >= 0) {
+      int need = 0;
+      ref[j] = wide_node(w, slot[j], need);
+      deepest = std::max(deepest, need);
+    } else {
+      ref[j] = ~((n.left << 3) | (-n.right));
+    }
+  }
+  DevBvh4& d = (*w.out)[(size_t)me];
+  for (int c = 0; c < 6; ++c) d.q[c] = make_float4(box[c][0], box[c][1], box[c][2], box[c][3]);
+  float f[4];
+  memcpy(f, ref, sizeof f);
+  d.q[6] = make_float4(f[0], f[1], f[2], f[3]);
+  d.q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+  stack_need = k - 1 + deepest;
+  return me;
+}
+
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
 constexpr int kMaxLdsTris = 320;      /* 320 * 64 B = 20 KiB of single-precision forms beside the 18 KiB the kernel keeps for values
@@ -315,14 +376,14 @@ constexpr size_t kMaxListEntries = 1 << 20; /* ... unless the lists of a launch 
 constexpr int kMaxCoverTris = 1 << 16;     /* meshes up to this size are rasterised into the tile grid to find the tiles they cover */
 constexpr int kMaxTilePlanTris = 1 << 22;  /* meshes up to this size get their tiles ordered by how crowded they are */
 constexpr int kAutoDeviceBvhTris = 4096; /* meshes from this size up never stay without a BVH */
-constexpr int kMaxLdsBvhNodes = 768;  /* 768 * 64 B = 48 KiB of inner nodes (~3000 triangles) */
+constexpr int kMaxLdsBvhNodes = 48 * 1024 / (int)sizeof(DevBvhNode);  /* 48 KiB of inner nodes (~3000 triangles) */
 
 template <bool COUNT, bool BVH, bool REFLECT, int STAGE, int KIND>
 void launch_one(size_t lds, dim3 grid, hipStream_t s, const RenderArgs& a, unsigned char* rgb, double* canvas) {
   hipLaunchKernelGGL((rt_trace_kernel<COUNT, BVH, REFLECT, STAGE, KIND>), grid, dim3(RT_TILE_W * RT_TILE_H), lds, s, cur->d_scene,
                      (const DevSphere*)cur->d_spheres, (const DevSpherePrimary*)cur->d_sph_primary, (const DevTri*)cur->d_tris,
                      (const DevTriPrimary*)cur->d_tri_primary, (const double*)cur->d_normals, (const rt_material*)cur->d_materials,
-                     (const DevBvh2*)cur->d_bvh, (const DevTriF*)cur->d_trif, (const DevSphereF*)cur->d_sphf, a,
+                     (const DevBvhNode*)cur->d_bvh, (const DevTriF*)cur->d_trif, (const DevSphereF*)cur->d_sphf, a,
                      cur->launch_tile_list, cur->launch_tile_mask, rgb, canvas,
                      cur->launch_counters ? cur->launch_counters : cur->d_counters);
 }
@@ -387,7 +448,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
       /* the traversal stacks, and in front of them the inner nodes if both fit while two workgroups still share
        * a CU's 160 KiB (the walk's register budget allows no more than two anyway) */
       const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)cur->scene.bvh_depth;
-      const size_t nodes = (size_t)cur->scene.n_bvh_nodes * sizeof(DevBvh2);
+      const size_t nodes = (size_t)cur->scene.n_bvh_nodes * sizeof(DevBvhNode);
       if (cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
         stage = 3;
         lds = nodes + stacks;
@@ -2474,7 +2535,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   if (cur->bvh_single_leaf) use_bvh = false; /* nothing to walk: the exhaustive loop is the walk */
   if (use_bvh) {
     depth = bvh_depth(sc->bvh_nodes, sc->n_bvh_nodes, 0, 0);
-    if (depth > RT_BVH_STACK) return RT_ERR_TOO_LARGE;
+    if (depth > 48) return RT_ERR_TOO_LARGE;
     if (nt >= (1 << 27)) return RT_ERR_TOO_LARGE;
     std::vector<char> used((size_t)nt, 0);
     for (int i = 0; i < sc->n_bvh_nodes; ++i) {
@@ -2613,6 +2674,19 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   /* device BVH: inner nodes only, each with both children's boxes.  The host boxes get an extra pad of
    * ~500 float ulps of the largest coordinate in play (mesh, camera, light), far more than rounding the ray
    * origin, its reciprocal direction and the slab products to single precision can move a slab distance. */
+#if RT_BVH_WIDE
+  std::vector<DevBvh4> hb;
+  if (use_bvh) {
+    WideBuild wb = {sc->bvh_nodes, 3e-5 * amax, &hb};
+    hb.reserve((size_t)sc->n_bvh_nodes / 3 + 1);
+    int need = 0;
+    (void)wide_node(wb, 0, need);
+    if (need > RT_BVH_STACK) return RT_ERR_TOO_LARGE;
+    depth = need; /* what the walk's stack has to hold */
+    n_bvh_inner = (int)hb.size();
+    if ((rc = upload(&cur->d_bvh, hb.data(), sizeof(DevBvh4) * hb.size())) != RT_OK) return rc;
+  }
+#else
   std::vector<DevBvh2> hb;
   if (use_bvh) {
     const double pad2 = 3e-5 * amax;
@@ -2649,6 +2723,7 @@ int rt_hip_upload_scene(const rt_scene* sc) {
     n_bvh_inner = n_inner;
     if ((rc = upload(&cur->d_bvh, hb.data(), sizeof(DevBvh2) * (size_t)n_inner)) != RT_OK) return rc;
   }
+#endif
 
   DevScene& d = cur->scene;
   d.pixel_size = sc->camera.pixel_size;
@@ -2809,9 +2884,11 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   DevTriF* trif_out;
   DevTriPrimary* prim_out;
   double* normals_out;
-  DevBvh2* nodes;
+  DevBvhNode* nodes = nullptr;
   const size_t nn = (size_t)n, ni = nn - 1;
-  if (!b.get(&tris_out, nn) || !b.get(&trif_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn) || !b.get(&nodes, ni)) return RT_ERR_HIP;
+  if (!b.get(&tris_out, nn) || !b.get(&trif_out, nn) || !b.get(&prim_out, nn) || !b.get(&normals_out, 3 * nn)) return RT_ERR_HIP;
+  /* four-wide nodes are allocated once their number is known */
+  if (!RT_BVH_WIDE && !b.get(&nodes, ni)) return RT_ERR_HIP;
   size_t sort_bytes = 0, scan_bytes = 0;
   HIP_TRY((hipError_t)g_sort.pairs(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, n, cur->stream));
   HIP_TRY((hipError_t)g_sort.sum(nullptr, &scan_bytes, nullptr, nullptr, (int)ni, cur->stream));
@@ -2870,34 +2947,77 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
                        walked, left, right, range_lo, range_hi, parent_of_node, parent_of_leaf);
     e = hipMemsetAsync(visits, 0, sizeof(unsigned) * ni, s);
   }
+#if !RT_BVH_WIDE
   if (e == hipSuccess) {
     size_t bytes = space_bytes;
     e = (hipError_t)g_sort.sum(sort_space, &bytes, walked, slot, (int)ni, s);
   }
+#endif
   if (e == hipSuccess) {
     hipLaunchKernelGGL(lbvh_fit_kernel, dim3((unsigned)((nn + LBVH_FIT_THREADS - 1) / LBVH_FIT_THREADS)), dim3(LBVH_FIT_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,
                        (const int*)range_lo, (const int*)range_hi, (const int*)parent_of_node, (const int*)parent_of_leaf,
                        (const float*)leaf_lo, (const float*)leaf_hi, node_lo, node_hi, node_depth, visits);
+#if RT_BVH_WIDE
+    /* which walked nodes become four-wide nodes (`visits` has served the fit and holds the flags now), and where */
+    unsigned* const wide = visits;
+    hipLaunchKernelGGL(lbvh_level_kernel, per_node, dim3(LBVH_THREADS), 0, s, n, (const int*)parent_of_node, (const unsigned*)walked, wide);
+    e = hipGetLastError();
+    if (e == hipSuccess) {
+      size_t bytes = space_bytes;
+      e = (hipError_t)g_sort.sum(sort_space, &bytes, wide, slot, (int)ni, s);
+    }
+#else
     hipLaunchKernelGGL(lbvh_emit_kernel, per_node, dim3(LBVH_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,
                        (const int*)range_lo, (const int*)range_hi, (const float*)leaf_lo, (const float*)leaf_hi,
                        (const float*)node_lo, (const float*)node_hi, (const unsigned*)walked, (const unsigned*)slot, nodes);
     e = hipGetLastError();
+#endif
+  }
+  int packed = 0;
+  unsigned last_slot = 0, last_flag = 0;
+  float ms = 0.f;
+#if RT_BVH_WIDE
+  /* the number of four-wide nodes is known now: room for them, then the nodes themselves */
+  hipEvent_t e_mid = nullptr;
+  if (e == hipSuccess) e = hipEventCreate(&e_mid);
+  if (e == hipSuccess) e = hipEventRecord(e_mid, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&last_slot, slot + (ni - 1), sizeof last_slot, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&last_flag, visits + (ni - 1), sizeof last_flag, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&packed, node_depth, sizeof packed, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  float ms_a = 0.f, ms_b = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_a, e0, e_mid);
+  const int n_walked = (int)(last_slot + last_flag);
+  if (e == hipSuccess && !b.get(&nodes, (size_t)(n_walked > 0 ? n_walked : 1))) e = hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipEventRecord(e_mid, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lbvh_emit4_kernel, per_node, dim3(LBVH_THREADS), 0, s, n, leaf_size, (const int*)left, (const int*)right,
+                       (const int*)range_lo, (const int*)range_hi, (const float*)leaf_lo, (const float*)leaf_hi,
+                       (const float*)node_lo, (const float*)node_hi, (const unsigned*)visits, (const unsigned*)slot, nodes);
+    e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipEventRecord(e1, s);
   if (e == hipSuccess) e = hipEventSynchronize(e1);
-  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_b, e_mid, e1);
+  ms = ms_a + ms_b; /* the kernels; the allocation in between is the caller's wall time */
+  if (e_mid) (void)hipEventDestroy(e_mid);
+  const int depth = (packed >> 8) & 255; /* subtrees a four-wide walk can have postponed at once */
+  const int levels = packed & 255;
+#else
+  if (e == hipSuccess) e = hipEventRecord(e1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
   if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-  int depth = 0;
-  unsigned last_slot = 0, last_walked = 0;
-  if (e == hipSuccess) e = hipMemcpy(&depth, node_depth, sizeof depth, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&packed, node_depth, sizeof packed, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(&last_slot, slot + (ni - 1), sizeof last_slot, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(&last_walked, walked + (ni - 1), sizeof last_walked, hipMemcpyDeviceToHost);
-  const int n_walked = (int)(last_slot + last_walked);
+  if (e == hipSuccess) e = hipMemcpy(&last_flag, walked + (ni - 1), sizeof last_flag, hipMemcpyDeviceToHost);
+  const int n_walked = (int)(last_slot + last_flag);
+  const int depth = packed & 255, levels = depth;
+#endif
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (!hip_ok(e, "device BVH build")) return RT_ERR_HIP;
-  if (depth < 1 || depth > RT_BVH_STACK) {
-    snprintf(g_err, sizeof g_err, "device BVH is %d levels deep; the walk's stack holds %d", depth, RT_BVH_STACK);
+  if (depth < 1 || depth > RT_BVH_STACK || levels >= 255) {
+    snprintf(g_err, sizeof g_err, "device BVH: %d levels, a walk may postpone %d subtrees; its stack holds %d", levels, depth, RT_BVH_STACK);
     return RT_ERR_TOO_LARGE;
   }
   /* hand over: the sorted triangle arrays and the nodes replace the scene's */
@@ -2925,7 +3045,7 @@ int rt_hip_build_bvh_device(int leaf_size, rt_bvh_device_info* info) {
   cur->tri_depth.clear();
   HIP_TRY(hipMemcpy(cur->d_scene, &cur->scene, sizeof(DevScene), hipMemcpyHostToDevice));
   cur->scene_serial++;
-  if (info) { info->n_nodes = n_walked; info->depth = depth; info->build_ms = ms; }
+  if (info) { info->n_nodes = n_walked; info->depth = levels; info->build_ms = ms; }
   return RT_OK;
 }
 
