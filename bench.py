@@ -11,13 +11,16 @@ Rank 0 prints one JSON line.
 
   value        total rays (primary + shadow + secondary: the reference's
                intersect_world call count) of all ranks / wall time, Mrays/s
+  value_cold   the same with only the W warm-up steps in front (no clock ramp)
   roofline     the trace kernel against the FP32 vector peak.  achieved = the
-               FLOPs the kernel EXECUTED (its own counters: single-precision
-               filter tests, double-precision confirms, box tests, ray set-up,
-               shading) / kernel time.  The exhaustive figure rays x
-               primitives x 45 (what the reference's loop over every object
-               costs) is reported beside it as algorithmic_equivalent; it is
-               not what the hardware did.
+               FLOPs the TIMED kernel executed / kernel time: the counters of a
+               counting build that skips what the production kernel skips
+               (RT_RENDER_COUNT_AS_RUN: background tiles are filled, not
+               traced; camera rays of waves that look past the mesh are not set
+               up), priced per test.  The exhaustive figure rays x primitives
+               x 45 (what the reference's loop over every object costs) is
+               reported beside it as algorithmic_equivalent; it is not what the
+               hardware did.
   cpu_baseline the reference itself (oracle/_ref, gcc -O2, one core) on the
                same workload, timed on this host
 """
@@ -53,7 +56,7 @@ FLOP_SPHERE_FILTER_PRIMARY = 36
 FLOP_PER_BOX_TEST = 18      # slab test (BVH node or mesh bounds)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 128 lanes x 2 x 2.4 GHz)
 PEAK_FP64_NO_FMA_TFLOPS = 39.3  # FP64 vector: 78.6 with FMA, half of it for a mul/add-only stream
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_cube_1080p.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_cube_1080p.json")
 LIGHTHOUSE_BIN = os.path.join(ROOT, "raytracer_amd", "data", "lighthouse_tris_f32.bin")
 CLI = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer_hip")
 
@@ -76,19 +79,29 @@ def git_commit():
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the headline kernel, from the committed summary of separate rocprofv3 --pmc passes (a
-    bench run cannot collect hardware counters itself), with the file and the commit it was taken at."""
+    """HBM bytes per launch of the headline kernel and the share of cycles its SIMDs' issue ports were busy with
+    vector instructions, from the committed summary of separate rocprofv3 --pmc passes (a bench run cannot collect
+    hardware counters itself), with the file and the commit it was taken at."""
     try:
         d = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
-        return int(d["derived_hbm_read_bytes_corrected_x2"] + d["derived_hbm_write_bytes"]), {"file": PMC_SUMMARY,
-                                                                                             "commit": d.get("_commit")}
+        return (int(d["derived_hbm_read_bytes_corrected_x2"] + d["derived_hbm_write_bytes"]),
+                {"file": PMC_SUMMARY, "commit": d.get("_commit")}, d.get("derived_valu_issue_busy"))
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, None, None
+
+
+def counted_as_run(hip, buf, **kw):
+    """rt_stats of the counting build told to skip what the production kernel skips (same image, same tests as the
+    timed kernel): what the roofline numerator is built from."""
+    st = R._ffi.Stats()
+    hip.render_device(buf.data_ptr(), R.make_params(count_rays=True, count_as_run=True, **kw), stats=st)
+    return st
 
 
 def executed_flops(st, n_spheres, brute):
-    """(single-precision FLOPs, double-precision FLOPs) of the work one launch really did, from the counting
-    build's counters.  Exhaustive kernels run the single-precision test on every triangle and confirm the
+    """(single-precision FLOPs, double-precision FLOPs) of the work one launch really did, from the counters of the
+    counting build run as the production kernel runs (counted_as_run: rays_primary = camera rays set up).
+    Exhaustive kernels run the single-precision test on every triangle and confirm the
     survivors in double precision; the BVH walk tests a leaf's triangles in double precision directly, and its
     camera rays run the single-precision test down their tile's list (of those, the tests that were not followed by
     a double-precision one are counted: a lower bound)."""
@@ -101,10 +114,13 @@ def executed_flops(st, n_spheres, brute):
     return f32, f64
 
 
-def roofline_of(st, n_spheres, n_tris, ms):
-    """The roofline object of one kernel launch that took `ms`."""
+def roofline_of(st, n_spheres, n_tris, ms, run=None):
+    """The roofline object of one kernel launch that took `ms`.  st: the counters of the reference's loop (every pixel
+    traced: ray counts, algorithmic_equivalent); run: the counters of what the timed kernel executes (counted_as_run);
+    without it st stands for both."""
     brute = st.accel_used == R._ffi.RT_ACCEL_BRUTE
-    f32, f64 = executed_flops(st, n_spheres, brute)
+    run = run or st
+    f32, f64 = executed_flops(run, n_spheres, brute)
     total = f32 + f64
     achieved = total / (ms * 1e-3) / 1e12
     # what this mix of instructions could reach at most: each part at its own peak
@@ -118,9 +134,10 @@ def roofline_of(st, n_spheres, n_tris, ms):
             "algorithmic_equivalent": {"flops_per_launch": int(exhaustive), "tflops": round(exhaustive / (ms * 1e-3) / 1e12, 3),
                                        "what": "rays x primitives x the full-path figure: the reference's loop over every "
                                                "object; not executed here (bounds, single-precision first tests, BVH)"},
-            "counters": {"tri_tests": st.prim_tests - st.sphere_tests, "tri_exact": st.tri_exact, "sphere_tests": st.sphere_tests,
-                         "sphere_exact": st.sphere_exact, "box_tests": st.node_tests, "primary": st.rays_primary,
-                         "shaded": st.rays_shadow, "secondary": st.rays_secondary}}
+            "counters": {"tri_tests": run.prim_tests - run.sphere_tests, "tri_exact": run.tri_exact, "sphere_tests": run.sphere_tests,
+                         "sphere_exact": run.sphere_exact, "box_tests": run.node_tests, "camera_rays_set_up": run.rays_primary,
+                         "shaded": run.rays_shadow, "secondary": run.rays_secondary,
+                         "what": "executed by the timed kernel (background tiles filled, not traced)"}}
 
 
 def time_launches(hip, buf, p, n, reps=3):
@@ -149,28 +166,32 @@ def side_measurements(hip, dev):
         hip.upload(R.stock_scene(scene, WIDTH, HEIGHT, tr))
         st = R._ffi.Stats()
         hip.render_device(buf.data_ptr(), R.make_params(accel=accel, count_rays=True), stats=st)
+        run = counted_as_run(hip, buf, accel=accel)
         ms = time_launches(hip, buf, R.make_params(accel=accel), 100 if accel != R._ffi.RT_ACCEL_BRUTE else 10)
         sc = hip.scene_counts()
-        rf = roofline_of(st, sc[0], sc[1], ms)
+        rf = roofline_of(st, sc[0], sc[1], ms, run)
         out[name] = {"rays": st.rays, "kernel_ms": round(ms, 5), "mrays_s": round(st.rays / ms / 1e3, 1), "roofline": rf}
     return out
 
 
-def full_size_configs(hip, dev):
+def full_size_configs(hip, dev, only=None):
     """The two multi-GPU configurations at full size on this one GPU: C4 (4K lighthouse, mesh reflective 0.3, BVH) and
     C5 (8K, 16 spp, cube + spheres, reflective)."""
     out = {}
     for name, scene, w, h, tr, sr, spp, accel, n in (
             ("C4_lighthouse_3840x2160_reflective_bvh", "lighthouse", 3840, 2160, 0.3, 0.0, 1, R._ffi.RT_ACCEL_BVH, 20),
             ("C5_cube_spheres_7680x4320_16spp_reflective", "cube_spheres", 7680, 4320, 0.3, 0.3, 4, R._ffi.RT_ACCEL_AUTO, 3)):
+        if only and not name.startswith(only):
+            continue
         hip.upload(R.stock_scene(scene, w, h, tr, sr))
         buf = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
         st = R._ffi.Stats()
         hip.render_device(buf.data_ptr(), R.make_params(spp_grid=spp, accel=accel, count_rays=True), stats=st)
+        run = counted_as_run(hip, buf, spp_grid=spp, accel=accel)
         ms = time_launches(hip, buf, R.make_params(spp_grid=spp, accel=accel), n, reps=2)
         sc = hip.scene_counts()
         out[name] = {"rays": st.rays, "kernel_ms": round(ms, 4), "mrays_s": round(st.rays / ms / 1e3, 1),
-                     "roofline": roofline_of(st, sc[0], sc[1], ms)}
+                     "roofline": roofline_of(st, sc[0], sc[1], ms, run)}
         del buf
     return out
 
@@ -307,6 +328,17 @@ def first_call_measurements():
         out["headline_frame_fresh_process"] = info if info else {"error": err}
         if info:
             out["first_call_ms"] = info.get("first_call_ms")
+        # the 1080p lighthouse (a frame that walks a BVH: the one whose tile plan can be tuned by measurement), one frame
+        # per process as the reference would render it (RT_RENDER_NO_TUNE) and with the plan tuned first
+        lh = {}
+        for key, extra in (("no_tune", []), ("tuned_first", ["--tune"])):
+            info, wall, err = run_json([CLI, "lighthouse", "--tris-f32", LIGHTHOUSE_BIN, "--size", str(WIDTH), str(HEIGHT), "--host-ppm",
+                                        "--no-count", "--json", "--out", os.path.join(tmp, "l.ppm")] + extra, 120)
+            lh[key] = ({k: info.get(k) for k in ("init_ms", "upload_ms", "tune_ms", "first_call_ms", "first_call_kernel_ms")}
+                       if info else {"error": err})
+            if info:
+                lh[key]["process_wall_s"] = round(wall, 4)
+        out["lighthouse_1080p_first_frame"] = lh
         hip_ppm, ref_ppm = os.path.join(tmp, "hip.ppm"), os.path.join(tmp, "ref.ppm")
         info, wall, err = run_json([CLI, "lighthouse", "--tris-f32", LIGHTHOUSE_BIN, "--json", "--out", hip_ppm], 120)
         c1 = {"hip_process_wall_s": round(wall, 4), "hip": info if info else {"error": err}}
@@ -488,31 +520,44 @@ def main():
         dist.all_reduce(my_rays)
     total_rays, _ = [int(x) for x in my_rays.tolist()]
     accel_used = "bvh" if st.accel_used == R._ffi.RT_ACCEL_BVH else "brute"
+    # the same rows counted as the timed kernel runs them (the roofline's numerator)
+    run = R._ffi.Stats()
+    hip.render_device(fx.target(0, 0).data_ptr(), R.make_params(max_depth=5, count_rays=True, count_as_run=True, band_rows=band_rows,
+                                                              n_ranks=world, rank=rank), stream=stream, stats=run)
 
     def render(target):
         hip.render_device(target.data_ptr(), p, stream=stream)
 
-    # The device's clocks come up over the first thousand-odd launches after any pause (the upload is one): that ramp
-    # belongs to the set-up, like the upload, not to the W warm-up steps or the K timed ones.
+    def timed_region():
+        """W warm-up steps, then K timed steps between barrier + synchronize on both sides; (wall s, event ms)."""
+        run_frames(render, fx, a.warmup)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hip.timer_start(stream)
+        held = run_frames(render, fx, a.steps)
+        hip.timer_stop(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        frames_held = torch.tensor([held], dtype=torch.float64, device="cpu" if rehearse else dev)
+        if world > 1:
+            dist.all_reduce(frames_held)
+        assert int(frames_held.item()) == a.steps, "every timed frame must have been put together on some rank"
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearse else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), hip.timer_ms()
+
+    # First as the protocol alone has it: W warm-up steps after the upload, K timed steps (value_cold).
+    dt_cold, _ = timed_region()
+    # The device's clocks come up over the first thousand-odd launches after any pause (the upload is one): with that
+    # ramp counted to the set-up, like the upload, the same region again (value).
     for _ in range(CLOCK_RAMP_LAUNCHES):
         hip.render_device(fx.target(0, 0).data_ptr(), p, stream=stream)
-    run_frames(render, fx, a.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    hip.timer_start(stream)
-    held = run_frames(render, fx, a.steps)
-    hip.timer_stop(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = hip.timer_ms()
-    frames_held = torch.tensor([held], dtype=torch.float64, device="cpu" if rehearse else dev)
-    if world > 1:
-        dist.all_reduce(frames_held)
-    assert int(frames_held.item()) == a.steps, "every timed frame must have been put together on some rank"
+    dt, ev_ms = timed_region()
     if world > 1:
         # the kernel alone (no exchange between launches), for the roofline line
         hip.timer_start(stream)
@@ -520,28 +565,32 @@ def main():
             hip.render_device(fx.target(0, 0).data_ptr(), p, stream=stream)
         hip.timer_stop(stream)
         ev_ms = hip.timer_ms() / 50 * a.steps
-    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
     line = None
     if rank == 0:
         kernel_ms = ev_ms / a.steps  # HIP events on the launch stream around the K launches
-        rf = roofline_of(st, scene.n_spheres, scene.n_tris, kernel_ms)
-        traffic, source = pmc_traffic()
+        rf = roofline_of(st, scene.n_spheres, scene.n_tris, kernel_ms, run)
+        traffic, source, issue_busy = pmc_traffic()
         rf["traffic"] = traffic
         rf["traffic_source"] = source
+        rf["valu_issue_busy"] = round(issue_busy, 4) if issue_busy is not None else None
         rf["kernel"] = "rt_trace_kernel"
         rf["note"] = ("bound: vector ALU (the scene sits in LDS/scalar cache, 3 B per pixel are written). achieved = FLOPs the "
-                      "kernel executed (counting build of the same kernel on the same rows) / kernel time; peak = the FP32 "
-                      "vector peak the metric names. The executed mix is single-precision FMA (filter and box tests) and "
-                      "double-precision mul/add without FMA (confirms, ray set-up, shading: bit parity with the reference); "
-                      "ceiling_of_issued_mix prices each part at its own peak (157.3 and 39.3 TFLOP/s). traffic = HBM "
-                      "bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)")
+                      "TIMED kernel executed / kernel time: counters of the counting build run as the production kernel runs "
+                      "(background tiles filled, not traced; only the camera rays that are set up), priced per test; peak = "
+                      "the FP32 vector peak the metric names. That peak of 157.3 TFLOP/s assumes packed single-precision FMA "
+                      "(v_pk_fma_f32) in every lane and cycle; this build uses neither packed FP32 (measured slower than "
+                      "the two plain FMAs it replaces on this part) nor FP64 FMA (bit parity with a reference binary that "
+                      "has none), so the executed mix is plain single-precision FMA (filter and box tests) and "
+                      "double-precision mul/add (confirms, ray set-up, shading); ceiling_of_issued_mix prices each part "
+                      "at its own peak (157.3 and 39.3 TFLOP/s). This 13 us frame is one launch at the latency of a "
+                      "single wave's dependent chain (a rank's share of it takes as long as the whole); the kernels that "
+                      "fill the chip are under full_size_configs_one_gpu and other_scenes_1080p. valu_issue_busy = "
+                      "SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles) and traffic = HBM bytes per launch (FETCH_SIZE "
+                      "x2 + WRITE_SIZE), both from separate rocprofv3 --pmc passes")
         line = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080 teapot scene; % of FP32 VALU peak",
             "value": round(total_rays * a.steps / dt / 1e6, 2),
+            "value_cold": round(total_rays * a.steps / dt_cold / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -562,8 +611,9 @@ def main():
                        "setup_launches": CLOCK_RAMP_LAUNCHES,
                        "note": "after any pause of the device (the scene upload is one) the first thousands of launches run "
                                "up to 12 % slower while the clocks come up (14.7 us per frame for launches 1-26, 14.1 for "
-                               "100-300, 13.0 from 1000 on), so the set-up ends with setup_launches untimed launches of "
-                               "the frame before the W warm-up steps and the K timed ones"},
+                               "100-300, 13.0 from 1000 on). value_cold is timed as the protocol alone has it (W warm-up "
+                               "steps after the upload, then K steps); for value the set-up ends with setup_launches "
+                               "untimed launches of the frame before the same W + K steps"},
             "roofline": rf,
         }
     del fx
@@ -589,8 +639,25 @@ def main():
                            ("C4_lighthouse_3840x2160_reflective_bvh", ("lighthouse", 3840, 2160, 0.3, 0.0, 1, R._ffi.RT_ACCEL_BVH, 50)),
                            ("C5_cube_spheres_7680x4320_16spp_reflective", ("cube_spheres", 7680, 4320, 0.3, 0.3, 4, R._ffi.RT_ACCEL_AUTO, 5))):
             multi[name] = gather_to_root(hip, dev, world, rank, *args, rehearse)
+        # C5 on ONE of these GPUs (rank 0 alone, the whole frame), so that the N-GPU figure above has its own 1-GPU
+        # figure from the same node and run beside it
+        one_gpu_ms = None
+        if rank == 0:
+            try:
+                one = full_size_configs(hip, dev, only="C5")
+                one_gpu_ms = next(iter(one.values()))["kernel_ms"]
+            except Exception as e:  # noqa: BLE001 - context only
+                multi["C5_one_gpu_error"] = f"{type(e).__name__}: {e}"
+        dist.barrier()
         if rank == 0:
             line["single_frame_gather_to_rank0"] = multi
+            c5 = multi.get("C5_cube_spheres_7680x4320_16spp_reflective")
+            if one_gpu_ms and c5:
+                line["scaling_c5"] = {"one_gpu_kernel_ms": one_gpu_ms, "n_gpus": world, "n_gpu_ms_per_frame": c5["ms_per_frame"],
+                                      "speedup": round(one_gpu_ms / c5["ms_per_frame"], 3),
+                                      "what": "8K x 16 spp cube + spheres, reflective: one frame rendered on all ranks and "
+                                              "gathered to rank 0 (wall time per frame, exchange included) against the "
+                                              "same frame's kernel time on rank 0's GPU alone"}
     hip.shutdown()
     if world > 1:
         dist.barrier()

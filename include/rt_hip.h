@@ -205,7 +205,14 @@ enum {
    * milliseconds, which pay off over a run of frames and cost a one-frame caller - the reference's main(): one
    * render(), one canvas.ppm, RayTracer.c:7236-7251 - more than the frame itself.  Such a caller sets this bit.
    * Images are the same either way. */
-  RT_RENDER_NO_TUNE = 2
+  RT_RENDER_NO_TUNE = 2,
+  /* With count_rays: the counters say what the production kernel of the same launch executes, not what the
+   * reference's loop does.  The two differ where the library knows a result without tracing: tiles that no camera
+   * ray can reach the mesh through are filled with color_at's black (RayTracer.c:1433-1435) instead of being
+   * traced, and a camera ray whose whole wave looks past the mesh bounds is never set up.  rays_primary is then the
+   * number of camera rays set up (not hsize x vsize x samples) and the test counters leave out the skipped work:
+   * the figures a roofline of the timed kernel has to be built from.  Images are the same. */
+  RT_RENDER_COUNT_AS_RUN = 4
 };
 
 typedef struct rt_stats {

@@ -24,6 +24,7 @@ RT_ACCEL_REFERENCE = 3
 
 RT_RENDER_FRAMES_OVERLAP = 1
 RT_RENDER_NO_TUNE = 2
+RT_RENDER_COUNT_AS_RUN = 4
 
 
 class Material(C.Structure):

@@ -301,6 +301,7 @@ int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
   return 1 + (l > r ? l : r);
 }
 
+#if RT_BVH_WIDE
 /* The caller's binary tree as four-wide nodes.  A wide node starts as the two children of a binary node; while it has
  * fewer than four slots, the inner child with the largest surface area is replaced by its own two children (the
  * child a ray is most likely to enter is the one worth opening).  Leaves stay as they are.  Boxes are the callers'
@@ -361,6 +362,8 @@ int wide_node(const WideBuild& w, int b, int& stack_need) {
   stack_need = k - 1 + deepest;
   return me;
 }
+
+#endif
 
 /* LDS staging limits: small meshes (brute force) and BVH node arrays that leave room for several
  * workgroups per CU */
@@ -2056,6 +2059,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
   a.rank = p->rank;
   a.rows = rows;
   a.ablate = (p->flags >> 8) & 0xff; /* development builds only (RT_ABLATE) */
+  a.count_as_run = (p->flags & RT_RENDER_COUNT_AS_RUN) ? 1 : 0;
   for (int i = 0; i < RT_MAX_SPP_GRID; ++i) a.sample_off[i] = (i + 0.5) / a.spp_grid; /* ref_harness / oracle: (i + 0.5) / G */
   const bool general = cur->general || p->accel == RT_ACCEL_REFERENCE;
   if (general && !cur->d_gen_scene) return RT_ERR_TOO_LARGE; /* too many objects for the every-ray-every-object kernel */

@@ -26,7 +26,7 @@ def _check(rc, what):
 
 
 def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=False, band_rows=1, n_ranks=1, rank=0,
-                flags=0, frames_overlap=False, no_tune=False):
+                flags=0, frames_overlap=False, no_tune=False, count_as_run=False):
     """rt_render_params; frames_overlap=True states that the caller keeps several frames in flight on different
     streams (RT_RENDER_FRAMES_OVERLAP); no_tune=True that the tile plan is to be used as it stands
     (RT_RENDER_NO_TUNE: a one-frame caller)."""
@@ -34,6 +34,8 @@ def make_params(max_depth=5, spp_grid=1, accel=_ffi.RT_ACCEL_AUTO, count_rays=Fa
         flags |= _ffi.RT_RENDER_FRAMES_OVERLAP
     if no_tune:
         flags |= _ffi.RT_RENDER_NO_TUNE
+    if count_as_run:  # with count_rays: the counters of what the production kernel executes (RT_RENDER_COUNT_AS_RUN)
+        flags |= _ffi.RT_RENDER_COUNT_AS_RUN
     return RenderParams(max_depth, spp_grid, accel, 1 if count_rays else 0, band_rows, n_ranks, rank, flags)
 
 
