@@ -394,9 +394,16 @@ int rt_hip_multi_devices(void);
 int rt_hip_multi_upload_scene(const rt_scene* scene);
 /* rt_hip_render over the group: the whole frame arrives in rgb_out (hsize * vsize * 3 bytes, host memory).
  * params->n_ranks must be 1 and rank 0 (the library deals the bands out: band_rows > 1 sets the band height,
- * otherwise 16 rows).  stats: counters summed over the devices, kernel_ms the longest kernel, exchange_ms the
- * gather. */
+ * otherwise 16 rows).  stats: counters summed over the devices, kernel_ms the longest a device rendered, exchange_ms
+ * from the end of device 0's own rendering until every device's rows are in place.  Unless RT_RENDER_NO_TUNE is set the
+ * devices' tile plans are tuned after the first frame has been delivered. */
 int rt_hip_render_multi(const rt_render_params* params, uint8_t* rgb_out, rt_stats* stats);
+/* In how many parts a device's rows travel (1 .. 4; 0 = the library decides per frame: two for frames of
+ * RT_MULTI_GPU_MIN_SAMPLES samples or more, else one).  With c parts a device is c ranks of the round-robin over
+ * n x c bands and renders them in c launches; part k leaves for device 0 while part k + 1 is being rendered, and
+ * device 0 places and copies out part after part, so the exchange and the copy to the host hide under the tail of
+ * the rendering.  The image does not depend on it. */
+int rt_hip_multi_set_chunks(int chunks);
 
 /* Where rank `rank`'s packed rows start in a buffer that holds every rank's rows, rank after rank (bytes). */
 size_t rt_hip_gather_offset(int hsize, int vsize, int band_rows, int n_ranks, int rank);

@@ -233,6 +233,7 @@ def hip_lib():
         L.rt_hip_multi_init.argtypes = [C.c_int]
         L.rt_hip_multi_upload_scene.argtypes = [C.POINTER(Scene)]
         L.rt_hip_render_multi.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+        L.rt_hip_multi_set_chunks.argtypes = [C.c_int]
         L.rt_hip_gather_offset.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_hip_gather_offset.restype = C.c_size_t
         L.rt_hip_place_bands_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -282,6 +283,7 @@ HIP_EXPORTS = [
     "rt_hip_multi_devices",
     "rt_hip_multi_upload_scene",
     "rt_hip_render_multi",
+    "rt_hip_multi_set_chunks",
     "rt_hip_gather_offset",
     "rt_hip_place_bands_device",
     "rt_hip_rank_rows",

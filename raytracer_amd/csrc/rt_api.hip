@@ -2257,7 +2257,12 @@ ncclComm_t g_comms[kMaxDevices] = {};
 unsigned char* g_gather = nullptr;  /* device 0: every rank's packed rows, rank after rank */
 unsigned char* g_final = nullptr;   /* device 0: the rows in image order */
 size_t g_gather_bytes = 0;
-hipEvent_t g_multi_ev[kMaxDevices] = {}; /* device r's kernel is done (recorded on its stream) */
+constexpr int kMaxChunks = 4;       /* a device's rows travel in up to this many parts, each as soon as it is rendered */
+int g_multi_chunks = 0;             /* rt_hip_multi_set_chunks: 0 = chosen per frame */
+hipEvent_t g_multi_ev[kMaxDevices][kMaxChunks] = {}; /* device r has rendered its part c (recorded on its stream) */
+hipStream_t g_multi_xfer[kMaxDevices] = {};          /* device r's transfers: beside its kernels, not behind them */
+hipEvent_t g_multi_done[kMaxChunks] = {};            /* device 0: part c of every device is in place */
+hipStream_t g_multi_copy = nullptr;                  /* device 0: the placed rows on their way to the host */
 hipEvent_t g_multi_t0 = nullptr, g_multi_t1 = nullptr; /* device 0: exchange + placement */
 
 bool rccl_ok(ncclResult_t r, const char* what) {
@@ -2336,9 +2341,15 @@ void multi_teardown() {
   for (int d = 0; d < g_multi_n; ++d) {
     if (g_comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_comms[d]);
     g_comms[d] = nullptr;
-    if (g_multi_ev[d]) { (void)hipSetDevice(d); (void)hipEventDestroy(g_multi_ev[d]); g_multi_ev[d] = nullptr; }
+    (void)hipSetDevice(d);
+    for (int c = 0; c < kMaxChunks; ++c)
+      if (g_multi_ev[d][c]) { (void)hipEventDestroy(g_multi_ev[d][c]); g_multi_ev[d][c] = nullptr; }
+    if (g_multi_xfer[d]) { (void)hipStreamDestroy(g_multi_xfer[d]); g_multi_xfer[d] = nullptr; }
   }
   if (g_multi_n > 0) (void)hipSetDevice(0);
+  for (int c = 0; c < kMaxChunks; ++c)
+    if (g_multi_done[c]) { (void)hipEventDestroy(g_multi_done[c]); g_multi_done[c] = nullptr; }
+  if (g_multi_copy) { (void)hipStreamDestroy(g_multi_copy); g_multi_copy = nullptr; }
   if (g_gather) (void)hipFree(g_gather);
   if (g_final) (void)hipFree(g_final);
   if (g_multi_t0) (void)hipEventDestroy(g_multi_t0);
@@ -2352,9 +2363,10 @@ void multi_teardown() {
 /* Rows of the gathered buffer (rank after rank, each rank's rows packed in increasing y) into image order:
  * out row y = rank (y / band_rows) % n_ranks's packed row.  16 bytes per thread where the row length allows. */
 __global__ __launch_bounds__(256) void place_bands_kernel(const unsigned char* __restrict__ gathered, unsigned char* __restrict__ out,
-                                                          int row_bytes, int vsize, int band_rows, int n_ranks) {
+                                                          int row_bytes, int vsize, int band_rows, int n_ranks, int rank_lo, int rank_hi) {
   const int y = blockIdx.y;
   const int band = y / band_rows, rank = band % n_ranks;
+  if (rank < rank_lo || rank >= rank_hi) return; /* only the rows of ranks rank_lo .. rank_hi - 1 (one part of a gather that arrives in parts) */
   const int packed = (band / n_ranks) * band_rows + (y - band * band_rows);
   /* rows of the ranks before `rank`: full rounds of bands, plus what the last, partial round gives them */
   const int stride = band_rows * n_ranks, full = vsize / stride, rem = vsize % stride;
@@ -3380,7 +3392,7 @@ int rt_hip_place_bands_device(const void* gathered_device, void* rgb_out_device,
   const dim3 grid((unsigned)((row_bytes + 256 * 16 - 1) / (256 * 16)), (unsigned)vsize);
   if (vsize > 65535) return RT_ERR_TOO_LARGE;
   hipLaunchKernelGGL(place_bands_kernel, grid, dim3(256), 0, s, (const unsigned char*)gathered_device, (unsigned char*)rgb_out_device,
-                     row_bytes, vsize, n_ranks > 1 ? band_rows : vsize, n_ranks);
+                     row_bytes, vsize, n_ranks > 1 ? band_rows : vsize, n_ranks, 0, n_ranks);
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }
@@ -3405,9 +3417,12 @@ int rt_hip_multi_init(int n_devices) {
   g_multi_n = n_devices;
   for (int d = 0; d < n_devices; ++d) {
     HIP_TRY(hipSetDevice(d));
-    HIP_TRY(hipEventCreateWithFlags(&g_multi_ev[d], hipEventDisableTiming));
+    for (int c = 0; c < kMaxChunks; ++c) HIP_TRY(hipEventCreateWithFlags(&g_multi_ev[d][c], hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&g_multi_xfer[d], hipStreamNonBlocking));
   }
   HIP_TRY(hipSetDevice(0));
+  for (int c = 0; c < kMaxChunks; ++c) HIP_TRY(hipEventCreateWithFlags(&g_multi_done[c], hipEventDisableTiming));
+  HIP_TRY(hipStreamCreateWithFlags(&g_multi_copy, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&g_multi_t0));
   HIP_TRY(hipEventCreate(&g_multi_t1));
   return rt_hip_set_device(0);
@@ -3423,6 +3438,18 @@ int rt_hip_multi_upload_scene(const rt_scene* scene) {
   return rt_hip_set_device(0);
 }
 
+int rt_hip_multi_set_chunks(int chunks) {
+  if (chunks < 0 || chunks > kMaxChunks) return RT_ERR_INVALID;
+  g_multi_chunks = chunks;
+  return RT_OK;
+}
+
+/* The frame over the group.  Every device's rows are dealt out once more into `chunks` parts (a device is `chunks`
+ * ranks of a round-robin over devices x chunks bands: rank c * n + d is part c of device d), one launch per part.
+ * All launches of all devices are enqueued first; nothing here waits for a device before the others have their work.
+ * Part c of device d leaves for device 0 on d's transfer stream as soon as d has rendered it - beside d's next part,
+ * not behind it - and device 0 puts the parts of every device in place and sends them on to the host one part after
+ * the other, so the gather and the copy to the host run under the tail of the rendering instead of after it. */
 int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* stats) {
   if (g_multi_n < 1) return RT_ERR_NOT_READY;
   if (!p || !rgb_out) return RT_ERR_INVALID;
@@ -3433,12 +3460,21 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
   if ((rc = check_params(p)) != RT_OK) return rc;
   const int W = cur->scene.hsize, H = cur->scene.vsize;
   if (H > 65535) return RT_ERR_TOO_LARGE;
+  const bool want = stats != nullptr, count = want && p->count_rays != 0;
+  /* parts: a frame of a millisecond or more per device hides its gather under its own tail in two parts; a short
+   * frame would only pay for the extra launches; the counting build keeps one set of counters per device */
+  const long long samples = (long long)W * H * p->spp_grid * p->spp_grid;
+  int chunks = g_multi_chunks > 0 ? g_multi_chunks : (samples >= RT_MULTI_GPU_MIN_SAMPLES ? 2 : 1);
+  if (count) chunks = 1;
   /* one tile row per band unless the caller says otherwise; fewer rows per band when the image is short, so
-   * that every device gets some (bands of 16 rows balance the compact lit region of mesh scenes) */
+   * that every part of every device gets some (bands of 16 rows balance the compact lit region of mesh scenes) */
   int band = p->band_rows > 1 ? p->band_rows : RT_TILE_H;
-  while (band > 1 && (H + band - 1) / band < 2 * n) band /= 2;
-  const size_t image_bytes = (size_t)W * H * 3;
+  while (chunks > 1 && (H + band - 1) / band < n * chunks) --chunks;
+  const int V = n * chunks;
+  while (band > 1 && (H + band - 1) / band < 2 * V) band /= 2;
+  const size_t row_bytes = (size_t)W * 3, image_bytes = row_bytes * H;
   if (image_bytes > g_gather_bytes) {
+    HIP_TRY(hipDeviceSynchronize());
     if (g_gather) (void)hipFree(g_gather);
     if (g_final) (void)hipFree(g_final);
     g_gather = g_final = nullptr;
@@ -3449,61 +3485,97 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
   }
   rt_render_params q = *p;
   q.band_rows = band;
-  q.n_ranks = n;
+  q.n_ranks = V;
   Enqueued enq[kMaxDevices];
-  size_t bytes[kMaxDevices], offset[kMaxDevices];
-  const bool want = stats != nullptr, count = want && p->count_rays != 0;
-  /* every device renders its bands: device 0 straight into its part of the gathered buffer */
+  size_t bytes[kMaxDevices][kMaxChunks], offset[kMaxDevices][kMaxChunks], local[kMaxDevices][kMaxChunks];
+  auto fail = [&](int code) { (void)rt_hip_set_device(0); return code; };
+  /* every device renders its parts: device 0 straight into its places of the gathered buffer */
   for (int d = 0; d < n; ++d) {
-    if ((rc = rt_hip_set_device(d)) != RT_OK) return rc;
-    if (!cur->have_scene || cur->scene.hsize != W || cur->scene.vsize != H) { (void)rt_hip_set_device(0); return RT_ERR_NOT_READY; }
-    q.rank = d;
-    const int rows = rt_hip_rank_rows(H, band, n, d);
-    bytes[d] = (size_t)rows * W * 3;
-    offset[d] = rt_hip_gather_offset(W, H, band, n, d);
-    unsigned char* target = g_gather;
-    if (d > 0) {
-      if (bytes[d] > cur->d_rgb_bytes) {
-        if (cur->d_rgb) (void)hipFree(cur->d_rgb);
-        cur->d_rgb = nullptr;
-        cur->d_rgb_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&cur->d_rgb, bytes[d] ? bytes[d] : 16));
-        cur->d_rgb_bytes = bytes[d];
-      }
-      target = cur->d_rgb;
+    if ((rc = rt_hip_set_device(d)) != RT_OK) return fail(rc);
+    if (!cur->have_scene || cur->scene.hsize != W || cur->scene.vsize != H) return fail(RT_ERR_NOT_READY);
+    size_t mine = 0;
+    for (int c = 0; c < chunks; ++c) {
+      const int v = c * n + d;
+      bytes[d][c] = (size_t)rt_hip_rank_rows(H, band, V, v) * row_bytes;
+      offset[d][c] = rt_hip_gather_offset(W, H, band, V, v);
+      local[d][c] = mine;
+      mine += bytes[d][c];
     }
-    /* plans, never tunes here: no device waits for another's measurements (they are made after the frame, below) */
-    if ((rc = render_enqueue(&q, target, nullptr, cur->stream, want, count, true, false, &enq[d])) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+    if (d > 0 && mine > cur->d_rgb_bytes) {
+      HIP_TRY(hipStreamSynchronize(cur->stream));
+      if (cur->d_rgb) (void)hipFree(cur->d_rgb);
+      cur->d_rgb = nullptr;
+      cur->d_rgb_bytes = 0;
+      if (!hip_ok(hipMalloc((void**)&cur->d_rgb, mine ? mine : 16), "hipMalloc (rows of a device)")) return fail(RT_ERR_HIP);
+      cur->d_rgb_bytes = mine;
+    }
+    if (want && !hip_ok(hipEventRecord(cur->ev0, cur->stream), "hipEventRecord")) return fail(RT_ERR_HIP);
+    for (int c = 0; c < chunks; ++c) {
+      q.rank = c * n + d;
+      unsigned char* const target = d == 0 ? g_gather + offset[0][c] : cur->d_rgb + local[d][c];
+      /* plans, never tunes here: no device waits for another's measurements (they are made after the frame, below) */
+      if ((rc = render_enqueue(&q, target, nullptr, cur->stream, false, count, true, false, &enq[d])) != RT_OK) return fail(rc);
+      if (!hip_ok(hipEventRecord(g_multi_ev[d][c], cur->stream), "hipEventRecord")) return fail(RT_ERR_HIP);
+    }
+    if (want && !hip_ok(hipEventRecord(cur->ev1, cur->stream), "hipEventRecord")) return fail(RT_ERR_HIP);
+    enq[d].timed = want;
+    enq[d].rows = rt_hip_rank_rows(H, band, n, d) /* what the device rendered in all */;
   }
-  /* one exchange step: every other device sends its rows to device 0 over its own link (a grouped send/recv:
-   * the gather has a fixed root and unequal parts, which no single RCCL collective expresses) */
   if ((rc = rt_hip_set_device(0)) != RT_OK) return rc;
-  hipStream_t s0 = cur->stream;
-  if (want) HIP_TRY(hipEventRecord(g_multi_t0, s0));
-  if (n > 1) {
-    RCCL_TRY(g_rccl.GroupStart());
-    bool group_ok = true; /* a group that was opened is closed whatever happens inside it */
-    for (int d = 1; d < n && group_ok; ++d) {
-      if (bytes[d] == 0) continue;
-      group_ok = rccl_ok(g_rccl.Send(g_ctx[d].d_rgb, bytes[d], ncclUint8, 0, g_comms[d], g_ctx[d].stream), "ncclSend") &&
-                 rccl_ok(g_rccl.Recv(g_gather + offset[d], bytes[d], ncclUint8, d, g_comms[0], s0), "ncclRecv");
+  hipStream_t x0 = g_multi_xfer[0];
+  if (want) HIP_TRY(hipEventRecord(g_multi_t0, cur->stream)); /* device 0's own rows are rendered */
+  for (int c = 0; c < chunks; ++c) {
+    /* one exchange step per part: every other device sends that part to device 0 over its own link (a grouped
+     * send/recv: the gather has a fixed root and unequal parts, which no single RCCL collective expresses) */
+    HIP_TRY(hipStreamWaitEvent(x0, g_multi_ev[0][c], 0));
+    if (n > 1) {
+      for (int d = 1; d < n; ++d) {
+        if (!hip_ok(hipSetDevice(d), "hipSetDevice")) return fail(RT_ERR_HIP);
+        if (!hip_ok(hipStreamWaitEvent(g_multi_xfer[d], g_multi_ev[d][c], 0), "hipStreamWaitEvent")) return fail(RT_ERR_HIP);
+      }
+      if (!hip_ok(hipSetDevice(0), "hipSetDevice")) return fail(RT_ERR_HIP);
+      RCCL_TRY(g_rccl.GroupStart());
+      bool group_ok = true; /* a group that was opened is closed whatever happens inside it */
+      for (int d = 1; d < n && group_ok; ++d) {
+        if (bytes[d][c] == 0) continue;
+        group_ok = rccl_ok(g_rccl.Send(g_ctx[d].d_rgb + local[d][c], bytes[d][c], ncclUint8, 0, g_comms[d], g_multi_xfer[d]), "ncclSend") &&
+                   rccl_ok(g_rccl.Recv(g_gather + offset[d][c], bytes[d][c], ncclUint8, d, g_comms[0], x0), "ncclRecv");
+      }
+      const ncclResult_t ended = g_rccl.GroupEnd();
+      (void)rt_hip_set_device(0);
+      if (!group_ok) return RT_ERR_HIP;
+      if (!rccl_ok(ended, "ncclGroupEnd")) return RT_ERR_HIP;
     }
-    const ncclResult_t ended = g_rccl.GroupEnd();
-    (void)rt_hip_set_device(0);
-    if (!group_ok) return RT_ERR_HIP;
-    if (!rccl_ok(ended, "ncclGroupEnd")) return RT_ERR_HIP;
+    const dim3 grid((unsigned)((row_bytes + 256 * 16 - 1) / (256 * 16)), (unsigned)H);
+    hipLaunchKernelGGL(place_bands_kernel, grid, dim3(256), 0, x0, (const unsigned char*)g_gather, g_final, (int)row_bytes, H,
+                       V > 1 ? band : H, V, c * n, (c + 1) * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g_multi_done[c], x0));
   }
-  if ((rc = rt_hip_place_bands_device(g_gather, g_final, W, H, band, n, s0)) != RT_OK) return rc;
-  if (want) HIP_TRY(hipEventRecord(g_multi_t1, s0));
-  HIP_TRY(hipMemcpyAsync(rgb_out, g_final, image_bytes, hipMemcpyDeviceToHost, s0));
-  HIP_TRY(hipStreamSynchronize(s0));
+  if (want) HIP_TRY(hipEventRecord(g_multi_t1, x0));
+  /* to the host part by part: part c is the n bands from band c * n on out of every V, i.e. runs of n * band rows
+   * every V * band rows - one strided copy, and one more for a run the bottom of the image cuts short */
+  for (int c = 0; c < chunks; ++c) {
+    HIP_TRY(hipStreamWaitEvent(g_multi_copy, g_multi_done[c], 0));
+    const size_t run_rows = (size_t)n * band, period_rows = (size_t)V * band, first_row = (size_t)c * n * band;
+    size_t full = 0;
+    while (first_row + full * period_rows + run_rows <= (size_t)H) ++full;
+    if (full > 0)
+      HIP_TRY(hipMemcpy2DAsync(rgb_out + first_row * row_bytes, period_rows * row_bytes, g_final + first_row * row_bytes,
+                               period_rows * row_bytes, run_rows * row_bytes, full, hipMemcpyDeviceToHost, g_multi_copy));
+    const size_t tail_row = first_row + full * period_rows;
+    if (tail_row < (size_t)H)
+      HIP_TRY(hipMemcpyAsync(rgb_out + tail_row * row_bytes, g_final + tail_row * row_bytes, ((size_t)H - tail_row) * row_bytes,
+                             hipMemcpyDeviceToHost, g_multi_copy));
+  }
+  HIP_TRY(hipStreamSynchronize(g_multi_copy));
   if (want) {
     rt_stats sum;
     memset(&sum, 0, sizeof sum);
     for (int d = 0; d < n; ++d) {
       rt_stats one;
       if ((rc = rt_hip_set_device(d)) != RT_OK) return rc;
-      if ((rc = render_collect(enq[d], cur->stream, &one)) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+      if ((rc = render_collect(enq[d], cur->stream, &one)) != RT_OK) return fail(rc);
       sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
       sum.prim_tests += one.prim_tests; sum.node_tests += one.node_tests; sum.sphere_tests += one.sphere_tests;
       sum.tri_exact += one.tri_exact; sum.sphere_exact += one.sphere_exact;
@@ -3518,14 +3590,16 @@ int rt_hip_render_multi(const rt_render_params* p, uint8_t* rgb_out, rt_stats* s
     sum.exchange_ms = ms;
     *stats = sum;
   }
-  /* the frame is out; a caller that will render more (no RT_RENDER_NO_TUNE) gets every device's plan tuned now */
+  /* the frame is out; a caller that will render more (no RT_RENDER_NO_TUNE) gets every device's plans tuned now */
   if (!(p->flags & RT_RENDER_NO_TUNE) && !count) {
     for (int d = 0; d < n; ++d) {
       if (rt_hip_set_device(d) != RT_OK) break;
-      q.rank = d;
       bool pending = false;
       for (const Context::TilePlan& t : cur->plans) pending = pending || (t.refine_left > 0 && t.key[0] == (long long)cur->scene_serial);
-      if (pending && (rc = rt_hip_tune(&q)) != RT_OK) { (void)rt_hip_set_device(0); return rc; }
+      for (int c = 0; pending && c < chunks; ++c) {
+        q.rank = c * n + d;
+        if ((rc = rt_hip_tune(&q)) != RT_OK) return fail(rc);
+      }
     }
     if ((rc = rt_hip_set_device(0)) != RT_OK) return rc;
   }

@@ -92,6 +92,27 @@ __device__ __forceinline__ d3 reflect3(d3 in, d3 n) {                           
   return sub3(in, scale3(two_n, d));
 }
 
+/* Experiment (A/B builds only, -DRT_SHADE_FMA=1): fused multiply-adds in lighting() and in the transform of a sphere's
+ * normal - never in an intersection test.  The default build contracts nothing: the reference binary has no FMA. */
+#ifndef RT_SHADE_FMA
+#define RT_SHADE_FMA 0
+#endif
+__device__ __forceinline__ double dot3s(d3 a, d3 b) {
+#if RT_SHADE_FMA
+  return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
+#else
+  return dot3(a, b);
+#endif
+}
+__device__ __forceinline__ d3 reflect3s(d3 in, d3 n) {
+#if RT_SHADE_FMA
+  const double d = -2.0 * dot3s(in, n);
+  return mk3(__builtin_fma(n.x, d, in.x), __builtin_fma(n.y, d, in.y), __builtin_fma(n.z, d, in.z));
+#else
+  return reflect3(in, n);
+#endif
+}
+
 /* pow(x, y) as lighting() and schlick() call it (:1310 with y = material.shininess, 200 in every stock material
  * (:710); :1480 with y = 5).  pow() is the one operation on the path whose last bits already differ between
  * the reference's libm and any device library, and its device expansion is the largest block of instructions
@@ -131,6 +152,25 @@ __device__ __forceinline__ d3 xform_vector(const double* __restrict__ m, d3 v) {
 __device__ __forceinline__ d3 xform_vector_transposed(const double* __restrict__ m, d3 v) {
   return mk3((v.x * m[0] + v.y * m[4]) + v.z * m[8], (v.x * m[1] + v.y * m[5]) + v.z * m[9],
              (v.x * m[2] + v.y * m[6]) + v.z * m[10]);
+}
+
+/* the shading variants of the two transforms a sphere's normal goes through (see RT_SHADE_FMA) */
+__device__ __forceinline__ d3 xform_point_s(const double* __restrict__ m, d3 p) {
+#if RT_SHADE_FMA
+  return mk3(__builtin_fma(p.z, m[2], __builtin_fma(p.y, m[1], __builtin_fma(p.x, m[0], m[3]))),
+             __builtin_fma(p.z, m[6], __builtin_fma(p.y, m[5], __builtin_fma(p.x, m[4], m[7]))),
+             __builtin_fma(p.z, m[10], __builtin_fma(p.y, m[9], __builtin_fma(p.x, m[8], m[11]))));
+#else
+  return xform_point(m, p);
+#endif
+}
+__device__ __forceinline__ d3 xform_vector_transposed_s(const double* __restrict__ m, d3 v) {
+#if RT_SHADE_FMA
+  return mk3(__builtin_fma(v.z, m[8], __builtin_fma(v.y, m[4], v.x * m[0])), __builtin_fma(v.z, m[9], __builtin_fma(v.y, m[5], v.x * m[1])),
+             __builtin_fma(v.z, m[10], __builtin_fma(v.y, m[6], v.x * m[2])));
+#else
+  return xform_vector_transposed(m, v);
+#endif
 }
 
 #endif

@@ -202,6 +202,10 @@ class MultiRenderer:
         self.width, self.height = scene.camera.hsize, scene.camera.vsize
         return self
 
+    def set_chunks(self, chunks):
+        """In how many parts a device's rows travel to device 0 (0: the library decides per frame)."""
+        _check(self._L.rt_hip_multi_set_chunks(int(chunks)), "rt_hip_multi_set_chunks")
+
     def render(self, params=None, stats=True, **kw):
         p = params or make_params(**kw)
         out = np.empty((self.height, self.width, 3), dtype=np.uint8)
