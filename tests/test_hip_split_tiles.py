@@ -30,7 +30,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                         (2, 100000, 1, {"RT_HIP_SPLIT_THRESHOLD": "0.3", "RT_HIP_SPLIT_REFINE": "12",
                                                                         "RT_HIP_LIST_LDS": "0"})])
 def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost, lists):
-    env = dict(os.environ, RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
+    # the switches exist in the development build of the library only (lib/librt_hip_dev.so, -DRT_DEV_SWITCHES)
+    env = dict(os.environ, RT_HIP_LIB="dev", RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
     r = subprocess.run([sys.executable, os.path.join(HERE, "split_tiles_child.py")], env=env, capture_output=True, text=True,
                        timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -2,6 +2,7 @@
 # WRITE_SIZE of the cube frame under a few environment settings (one rocprofv3 --pmc pass each).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export RT_HIP_LIB=dev  # the RT_HIP_* switches exist in the development build only
 for cfg in "default" "RT_HIP_COVER_TILES=0" "RT_HIP_TILE_MASKS=0" "RT_HIP_LIGHT_PER_BLOCK=4" "RT_HIP_TILE_PLAN=0"; do
   out=gpurun_out/wt_$(echo $cfg | tr '=' '_')
   rm -rf $out
