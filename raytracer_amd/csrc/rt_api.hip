@@ -113,6 +113,7 @@ struct Context {
    * and as the camera sees them (pixels; NaN: a corner beside or behind the camera) */
   std::vector<double> sph_inv, sph_norm, sph_world, sph_xy;
   double host_light[3] = {0, 0, 0};
+  std::vector<int32_t> sph_upload_index; /* device sphere k is the caller's sphere sph_upload_index[k] */
   std::vector<DevTriF> host_trif; /* meshes of up to kMaxListTris triangles without spheres: the single-precision forms as
                                      uploaded (the per-tile lists of plan_tiles hold copies of them) */
   std::vector<int32_t> host_tri_order; /* with host_trif: every triangle's position in the world's object list (the tie-break of hit()) */
@@ -838,11 +839,32 @@ int rt_hip_upload_scene(const rt_scene* sc) {
   }
 
   free_scene();
+  /* Device order of the spheres: smallest first (by the extent of the forward transform).  hit() is decided by
+   * (t, list position), whatever order the spheres are looked at in (every sphere carries its position), and a
+   * small sphere that a ray hits usually lies in front of the large ones (floors, walls): once it has been solved,
+   * the single-precision test rules those out as lying beyond the hit. */
+  std::vector<int> sph_perm((size_t)ns);
+  {
+    std::vector<double> extent((size_t)ns, INFINITY);
+    for (int i = 0; i < ns; ++i) {
+      sph_perm[i] = i;
+      double fwd[16];
+      if (invert4(sc->sph_inv + 16 * (size_t)i, fwd)) {
+        double e2 = 0.0;
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) e2 += fwd[4 * r + c] * fwd[4 * r + c];
+        if (std::isfinite(e2)) extent[i] = e2;
+      }
+    }
+    std::stable_sort(sph_perm.begin(), sph_perm.end(), [&](int x, int y) { return extent[x] < extent[y]; });
+  }
+  cur->sph_upload_index.assign(sph_perm.begin(), sph_perm.end());
   std::vector<DevSphere> hs((size_t)(ns > 0 ? ns : 1));
-  for (int i = 0; i < ns; ++i) {
-    memcpy(hs[i].inv, sc->sph_inv + 16 * (size_t)i, 12 * sizeof(double));
-    hs[i].material = sc->sph_material[i];
-    hs[i].order = sc->sph_order[i];
+  for (int k = 0; k < ns; ++k) {
+    const int i = sph_perm[k];
+    memcpy(hs[k].inv, sc->sph_inv + 16 * (size_t)i, 12 * sizeof(double));
+    hs[k].material = sc->sph_material[i];
+    hs[k].order = sc->sph_order[i];
   }
   std::vector<DevTri> ht((size_t)(nt > 0 ? nt : 1));
   std::vector<double> hn((size_t)(nt > 0 ? nt : 1) * 3);
@@ -1298,7 +1320,9 @@ const char* rt_hip_last_error(void) { return g_err; }
  * triangle list, whose triangle numbers lie from word info[4] + 16 * info[5] + offset on (rt_kernels.hip.inc:
  * stage_list).  info: 0 words, 1 entries, 2 mesh entries, 3 mask offset, 4 list_forms, 5 list_total, 6 tiles per
  * image row, 7 light tiles are background, 8 BVH in use, 9 triangles are in the scene's BVH leaf order (1) or as
- * uploaded (0).  RT_ERR_TOO_LARGE: cap_words is too small (info[0] says how many). */
+ * uploaded (0).  Behind the plan's words follow, one word per sphere, the caller's number of device sphere k (the
+ * masks count spheres in device order: smallest first).  RT_ERR_TOO_LARGE: cap_words is too small (info[0] plus the
+ * number of spheres are needed). */
 int rt_hip_debug_plan_host(const rt_scene* sc, const rt_render_params* p, int32_t* words, size_t cap_words, int64_t info[10]) {
   if (!sc || !p || !info) return RT_ERR_INVALID;
   static Context scratch;
@@ -1335,8 +1359,11 @@ int rt_hip_debug_plan_host(const rt_scene* sc, const rt_render_params* p, int32_
     info[7] = a.light_is_background;
     info[8] = bvh ? 1 : 0;
     info[9] = cur->scene.n_bvh_nodes > 0 ? 1 : 0;
-    if (w.size() > cap_words) rc = RT_ERR_TOO_LARGE;
-    else if (words && !w.empty()) memcpy(words, w.data(), sizeof(int32_t) * w.size());
+    if (w.size() + cur->sph_upload_index.size() > cap_words) rc = RT_ERR_TOO_LARGE;
+    else if (words) {
+      if (!w.empty()) memcpy(words, w.data(), sizeof(int32_t) * w.size());
+      for (size_t k = 0; k < cur->sph_upload_index.size(); ++k) words[w.size() + k] = cur->sph_upload_index[k];
+    }
   }
   g_host_only = false;
   scratch = Context{};

@@ -61,6 +61,8 @@ class Plan:
         (self.n_words, self.entries, self.heavy, self.mask_offset, self.list_forms, self.list_total, self.tiles_x,
          self.light_background, self.bvh, self.leaf_order) = [int(v) for v in info]
         self.words = words[: self.n_words]
+        # the masks count spheres in the device's order: device sphere k is the scene's sphere sphere_of_device[k]
+        self.sphere_of_device = [int(v) for v in words[self.n_words: self.n_words + scene.n_spheres]]
         self.entry_of_tile = {}
         for k in range(self.entries):
             self.entry_of_tile.setdefault(int(self.words[k]) & 0x3FFFFF, []).append(k)
@@ -90,11 +92,11 @@ def part_rect(lg, part):
     return x0, y0, w, h
 
 
-def device_numbers(scene, leaf_order):
+def device_numbers(scene, leaf_order, sphere_of_device):
     """world-list position -> ('tri' | 'sph', number the device knows the primitive by)"""
     out = {}
-    for i in range(scene.n_spheres):
-        out[int(scene.sph_order[i])] = ("sph", i)
+    for k, i in enumerate(sphere_of_device):
+        out[int(scene.sph_order[i])] = ("sph", k)
     device_of = {int(scene.bvh_tri[k]): k for k in range(scene.n_tris)} if leaf_order else None
     for i in range(scene.n_tris):
         out[int(scene.tri_order[i])] = ("tri", device_of[i] if device_of else i)
@@ -103,7 +105,8 @@ def device_numbers(scene, leaf_order):
 
 def check_scene(scene, accel=_ffi.RT_ACCEL_BRUTE):
     plan = Plan(scene, accel=accel)
-    names = device_numbers(scene, plan.leaf_order)
+    names = device_numbers(scene, plan.leaf_order, plan.sphere_of_device)
+    sph_device_of = {i: k for k, i in enumerate(plan.sphere_of_device)}
     L = O.lib()
     nt, ns = scene.n_tris, scene.n_spheres
     soa = np.ctypeslib.as_array(scene.tri_soa, shape=(12, nt)).copy() if nt else np.zeros((12, 0))
@@ -174,11 +177,12 @@ def check_scene(scene, accel=_ffi.RT_ACCEL_BRUTE):
                     else:
                         assert (m[1] >> j) & 1, f"pixel ({x}, {y}): blocker {j} is not in the shadow mask"
             for i in range(ns):
-                if kind == "sph" and i == number:
+                j = sph_device_of[i]
+                if kind == "sph" and j == number:
                     continue
                 if L.rto_intersect_sphere((C.c_double * 16)(*inv[i]), C.byref(sray), roots) and any(0.0 <= r_ < dist for r_ in roots):
                     shadow_checks += 1
-                    assert (m[3] >> i) & 1, f"pixel ({x}, {y}): sphere {i} is not in the shadow mask"
+                    assert (m[3] >> j) & 1, f"pixel ({x}, {y}): sphere {j} is not in the shadow mask"
     return plan, hits, shadow_checks
 
 
