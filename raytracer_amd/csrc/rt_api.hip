@@ -261,7 +261,8 @@ int upload(void** dst, const void* src, size_t bytes) {
 }
 
 /* The single-precision form of a sphere.  inv: rows 0..2 of inverse(transform); origin: the camera origin;
- * radius as for rt_make_trif.  The filter compares |o' x d'|^2 with |d'|^2.  With eps = 2^-24, Mn = the Frobenius norm
+ * radius as for rt_make_trif.  The filter compares |o' x d'|^2 with |d'|^2 in object space rotated by Q^T (inv = Q U,
+ * DevSphereF): norms and products are those of inv o + t and inv d, the bounds below hold for the shorter sums a fortiori.  With eps = 2^-24, Mn = the Frobenius norm
  * of the linear part of inv, tn = |translation|, Omax = Mn radius + tn >= |o'|, |d| = 1:
  *   |o'_f - o'| <= 6 eps Omax, |d'_f - d'| <= 5 eps Mn (four resp. three fused products of once-rounded values),
  *   |(o' x d')_f - o' x d'| <= 6 eps Omax Mn + 5 eps Omax Mn + 7 eps Omax Mn = 18 eps Omax Mn =: Ec.
@@ -278,9 +279,45 @@ void make_spheref(const double* inv, const double* origin, double radius, DevSph
   const double omax = std::fmax(mn * radius + tn, 1.0);
   const double e = 24.0 * 5.9604644775390625e-8 * omax * std::fmax(mn, 1.0);
   const double k = (2.0 * mn * e + e * e) * 1.0001 + 1e-30;
-  for (int i = 0; i < 12; ++i) out->inv[i] = (float)inv[i];
-  for (int r = 0; r < 3; ++r)
-    out->po[r] = (float)(((origin[0] * inv[4 * r] + origin[1] * inv[4 * r + 1]) + origin[2] * inv[4 * r + 2]) + inv[4 * r + 3]);
+  /* inv's linear part A = Q U by Gram-Schmidt on its columns (A is invertible: the upload has inverted it) */
+  double a[3][3], q[3][3], u[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) a[c][r] = inv[4 * r + c]; /* a[c] = column c */
+  bool qr_ok = true;
+  for (int c = 0; c < 3; ++c) {
+    double v[3] = {a[c][0], a[c][1], a[c][2]};
+    for (int pass = 0; pass < 2; ++pass) /* twice: keeps Q orthogonal to rounding for the flattened spheres too */
+      for (int j = 0; j < c; ++j) {
+        const double p = q[j][0] * v[0] + q[j][1] * v[1] + q[j][2] * v[2];
+        u[j][c] += p;
+        for (int r = 0; r < 3; ++r) v[r] -= p * q[j][r];
+      }
+    const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (!(len > 1e-9 * mn) || !std::isfinite(len)) { qr_ok = false; break; }
+    u[c][c] = len;
+    for (int r = 0; r < 3; ++r) q[c][r] = v[r] / len;
+  }
+  if (qr_ok) { /* Q U must give A back and Q must be orthogonal, both far inside the test's margins */
+    double worst = 0.0;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) {
+        double back = 0.0, dot = 0.0;
+        for (int j = 0; j < 3; ++j) { back += q[j][r] * u[j][c]; dot += q[c][j] * q[r][j]; }
+        worst = std::fmax(worst, std::fabs(back - a[c][r]) / mn);
+        worst = std::fmax(worst, std::fabs(dot - (c == r ? 1.0 : 0.0)));
+      }
+    qr_ok = worst < 1e-11;
+  }
+  double tq[3] = {0, 0, 0};
+  if (qr_ok) {
+    for (int j = 0; j < 3; ++j) tq[j] = q[j][0] * inv[3] + q[j][1] * inv[7] + q[j][2] * inv[11];
+  }
+  out->u[0] = (float)u[0][0]; out->u[1] = (float)u[0][1]; out->u[2] = (float)u[0][2];
+  out->u[3] = (float)u[1][1]; out->u[4] = (float)u[1][2]; out->u[5] = (float)u[2][2];
+  for (int r = 0; r < 3; ++r) {
+    out->t[r] = (float)tq[r];
+    out->po[r] = (float)(((origin[0] * u[r][0] + origin[1] * u[r][1]) + origin[2] * u[r][2]) + tq[r]);
+  }
   out->k = (omax * mn < 1e15 && k < 1e30) ? (float)k : INFINITY; /* NaN compares false: infinite */
   /* for the "outside and leading away" test of sphere_filter: norms rounded up, and the camera origin's own c,
    * which the host knows in double precision (with the reference's expression, RayTracer.c:927) */
@@ -298,6 +335,11 @@ void make_spheref(const double* inv, const double* origin, double radius, DevSph
                      inv[2] * (inv[4] * inv[9] - inv[5] * inv[8]);
   const double sigma_min = mn > 0 ? std::fabs(det) / (mn * mn) : 0.0;
   out->self_ok = (2.0 * RT_EPSILON * sigma_min > 1e3 * 4e-16 * mn * std::fmax(radius, 1.0) && sigma_min > 1e-6) ? 1.0f : 0.0f;
+  if (!qr_ok) { /* every comparison of sphere_f32 is then false: the double-precision routine decides */
+    out->k = INFINITY;
+    out->mn = INFINITY;
+    out->primary_outside = out->self_ok = 0.0f;
+  }
 }
 
 int bvh_depth(const rt_bvh_node* nodes, int n, int i, int guard) {
