@@ -77,6 +77,9 @@ struct Context {
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
   int part_min_lg = 2;      /* entries split into at least 2^this parts get lists of their own */
+  int coop_min_lg = 2;      /* ... and from 2^this parts on whole waves render them (RenderArgs.coop_min_lg; 0: never) */
+  int coop_shadow_per_lane = 32; /* such a part's shadow rays run down a list of up to this many possible blockers per lane
+                                    that holds one of its pixels (2^lg lanes), instead of walking */
   int walk_shadow_max = 0;  /* walks: a whole tile's shadow rays run down their block's list if it has at most this many triangles */
   int part_shadow_max = 0;  /* ... and lists for their shadow rays up to this length (0: none, the default: with lists of
                                up to 48 or 96 the lighthouse frames are the same to the microsecond, and making them costs
@@ -141,6 +144,7 @@ struct Context {
     std::unordered_map<int32_t, PartLists> part_cache; /* by entry: the lists of parts made so far (while refinements are pending) */
     bool part_lists = false;       /* walks: a part of a tile split into four or more gets lists of its own rectangle */
     int part_shadow_max = 0;       /* ... and a shadow rays' list if that has at most this many triangles */
+    int coop_min_lg = 0, coop_shadow_per_lane = 0; /* as in the context when the plan was made */
     int rows = 0, band_rows = 1, n_ranks = 1, rank = 0; /* the launch's packed rows and how they map to image rows */
     size_t mask_offset = 0;        /* d_list + mask_offset: four 64-bit masks per entry (0: none): the triangles a camera
                                       ray of the tile can hit, those a shadow ray from such a hit can, and the same for spheres */
@@ -564,6 +568,7 @@ int render_enqueue(const rt_render_params* p, unsigned char* d_rgb, double* d_ca
   a.rows = rows;
   a.ablate = (p->flags >> 8) & 0xff; /* development builds only (RT_ABLATE) */
   a.count_as_run = (p->flags & RT_RENDER_COUNT_AS_RUN) ? 1 : 0;
+  a.coop_min_lg = cur->coop_min_lg;
   for (int i = 0; i < RT_MAX_SPP_GRID; ++i) a.sample_off[i] = (i + 0.5) / a.spp_grid; /* ref_harness / oracle: (i + 0.5) / G */
   const bool general = cur->general || p->accel == RT_ACCEL_REFERENCE;
   if (general && !cur->d_gen_scene) return RT_ERR_TOO_LARGE; /* too many objects for the every-ray-every-object kernel */
@@ -730,6 +735,8 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_WALK_SHADOW_MAX")) cur->walk_shadow_max = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_MIN_LG")) cur->part_min_lg = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_COOP")) cur->coop_min_lg = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_COOP_SHADOW")) cur->coop_shadow_per_lane = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_PART_SHADOW_MAX")) cur->part_shadow_max = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_SPLIT_THRESHOLD")) cur->split_threshold = std::fmax(0.1, std::fmin(0.99, atof(e)));
