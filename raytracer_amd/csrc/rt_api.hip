@@ -73,6 +73,7 @@ struct Context {
   bool tile_plan = true;   /* order tiles mesh-first (scheduling hint) */
   bool use_lds = true;
   bool lds_stack = true;
+  bool lds_nodes = true;  /* a small tree's inner nodes are copied to LDS (development switch RT_HIP_LDS_NODES) */
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
@@ -505,7 +506,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
        * a CU's 160 KiB (the walk's register budget allows no more than two anyway) */
       const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)cur->scene.bvh_depth;
       const size_t nodes = (size_t)cur->scene.n_bvh_nodes * sizeof(DevBvhNode);
-      if (cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
+      if (cur->lds_nodes && cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
         stage = 3;
         lds = nodes + stacks;
         lds = fit_lists(lds, kMaxLdsPerWorkgroup); /* longer lists are read from memory */
@@ -743,6 +744,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_MAX_LG")) cur->split_max_lg = std::max(0, std::min(6, atoi(e)));
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
+  if (const char* e = getenv("RT_HIP_LDS_NODES")) cur->lds_nodes = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */
   if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) {
     const int v = atoi(e);
