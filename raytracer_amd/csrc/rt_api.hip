@@ -163,6 +163,7 @@ struct Context {
   const unsigned long long* launch_tile_mask = nullptr; /* likewise: per-entry pairs of triangle masks, or nullptr */
   TilePlan* launch_plan = nullptr;           /* the plan it came from (plan_tiles), nullptr for an unplanned launch */
   size_t launch_lds = 0;                     /* dynamic LDS per workgroup of the last launch() */
+  int launch_waves = 0;                      /* waves per SIMD its kernel is built for (walks; 0: not a walk) */
   unsigned long long* launch_counters = nullptr; /* counters argument of the launch being issued (nullptr: d_counters) */
   void* d_tri_primary = nullptr;
   void* d_sph_primary = nullptr;
@@ -455,6 +456,7 @@ void launch_family(bool bvh, int stage, int kind, size_t lds, dim3 grid, hipStre
                    double* canvas) {
   if (bvh) { /* a walk always has triangles */
     if (stage == 3) launch_kind<true, REFLECT, 3>(kind, lds, grid, s, a, rgb, canvas);
+    else if (stage == 5) launch_kind<true, false, 5>(kind, lds, grid, s, a, rgb, canvas); /* without mirrors only */
     else if (stage == 4) launch_kind<true, REFLECT, 4>(kind, lds, grid, s, a, rgb, canvas);
     else launch_kind<true, REFLECT, 0>(kind, 0, grid, s, a, rgb, canvas);
   } else if (kind == 1) {
@@ -506,10 +508,16 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
        * a CU's 160 KiB (the walk's register budget allows no more than two anyway) */
       const size_t stacks = (size_t)RT_TILE_W * RT_TILE_H * sizeof(int2) * (size_t)cur->scene.bvh_depth;
       const size_t nodes = (size_t)cur->scene.n_bvh_nodes * sizeof(DevBvhNode);
-      if (cur->lds_nodes && cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && nodes + stacks <= kMaxLdsPerWorkgroup) {
+      /* a tree small enough for LDS has references of 16 bits and stack entries of 4 bytes (bvh_walk, LSTACK == 2) */
+      const size_t stacks4 = stacks / 2;
+      if (cur->lds_nodes && cur->scene.n_bvh_nodes <= kMaxLdsBvhNodes && cur->scene.n_tris < 4096 && nodes + stacks4 <= kMaxLdsPerWorkgroup) {
         stage = 3;
-        lds = nodes + stacks;
-        lds = fit_lists(lds, kMaxLdsPerWorkgroup); /* longer lists are read from memory */
+        lds = nodes + stacks4;
+        /* the plain walk runs three workgroups per CU if its LDS lets it (longer lists are read from memory); with
+         * mirrors the registers allow two */
+        const bool many = !reflect && a.n_heavy > 4 * cur->n_cu && nodes + stacks4 <= (size_t)160 * 1024 / 3 - 4096;
+        if (many) stage = 5; /* the same kernel held to the registers of three waves per SIMD */
+        lds = fit_lists(lds, many ? (size_t)160 * 1024 / 3 : kMaxLdsPerWorkgroup);
       } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3)) {
         /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
          * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
@@ -526,6 +534,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
   }
   const int kind = (!bvh && cur->scene.n_tris == 0) ? 1 : (cur->scene.n_spheres == 0 ? 2 : 0);
   cur->launch_lds = lds;
+  cur->launch_waves = !bvh ? 0 : (reflect || stage == 3 ? RT_MIN_WAVES_BVH : (stage == 5 ? RT_MIN_WAVES_BVH_LDS : RT_MIN_WAVES_BVH_PLAIN));
   if (reflect) launch_family<true>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
   else launch_family<false>(bvh, stage, kind, lds, grid, s, a, rgb, canvas);
 }
