@@ -577,15 +577,17 @@ def main():
         rf["note"] = ("bound: vector ALU (the scene sits in LDS/scalar cache, 3 B per pixel are written). achieved = FLOPs the "
                       "TIMED kernel executed / kernel time: counters of the counting build run as the production kernel runs "
                       "(background tiles filled, not traced; only the camera rays that are set up), priced per test; peak = "
-                      "the FP32 vector peak the metric names. That peak of 157.3 TFLOP/s assumes packed single-precision FMA "
-                      "(v_pk_fma_f32) in every lane and cycle; this build uses neither packed FP32 (measured slower than "
-                      "the two plain FMAs it replaces on this part) nor FP64 FMA (bit parity with a reference binary that "
-                      "has none), so the executed mix is plain single-precision FMA (filter and box tests) and "
-                      "double-precision mul/add (confirms, ray set-up, shading); ceiling_of_issued_mix prices each part "
-                      "at its own peak (157.3 and 39.3 TFLOP/s). This 13 us frame is one launch at the latency of a "
-                      "single wave's dependent chain (a rank's share of it takes as long as the whole); the kernels that "
-                      "fill the chip are under full_size_configs_one_gpu and other_scenes_1080p. valu_issue_busy = "
-                      "SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles) and traffic = HBM bytes per launch (FETCH_SIZE "
+                      "the FP32 vector peak the metric names: 157.3 TFLOP/s = a fused multiply-add in 32 lanes of each of "
+                      "1024 SIMDs per cycle (a 64-lane instruction holds its SIMD's issue port for 2 cycles). FP64 runs at "
+                      "half that rate, and this build uses no FP64 FMA (bit parity with a reference binary that has "
+                      "none), so the executed mix is single-precision FMA (filter and box tests) and double-precision "
+                      "mul/add (confirms, ray set-up, shading); ceiling_of_issued_mix prices each part at its own peak "
+                      "(157.3 and 39.3 TFLOP/s). This 13 us frame is one launch at the latency of a single wave's "
+                      "dependent chain (a rank's share of it takes as long as the whole); the kernels that fill the chip "
+                      "are under full_size_configs_one_gpu and other_scenes_1080p. valu_issue_busy = the cycles the "
+                      "executed vector instructions hold their SIMD's issue port (2 per instruction, 4 for an FP64 "
+                      "add/mul/fma, 8 or 16 for a transcendental; by instruction class from SQ_INSTS_VALU_*) / (1024 "
+                      "SIMDs x kernel cycles), and traffic = HBM bytes per launch (FETCH_SIZE "
                       "x2 + WRITE_SIZE), both from separate rocprofv3 --pmc passes")
         line = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080 teapot scene; % of FP32 VALU peak",
