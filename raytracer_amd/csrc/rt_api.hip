@@ -499,7 +499,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
       stage = 0; /* camera rays read their tile's list (from the workgroup's copy in LDS if it fits), the others the whole
                     array through scalar loads */
       /* three workgroups per CU (the large-mesh kernel runs three waves per SIMD) beside the kernel's own 18 KiB */
-      lds = fit_lists(RT_PARK_BYTES, (size_t)160 * 1024 / 3) - RT_PARK_BYTES;
+      lds = fit_lists(RT_PARK_BYTES, (size_t)160 * 1024 / RT_MIN_WAVES_EXHAUSTIVE_LARGE) - RT_PARK_BYTES;
     } else if (!bvh && cur->scene.n_tris > 0 && cur->scene.n_tris <= kMaxLdsTris) {
       stage = 1;
       lds = (size_t)cur->scene.n_tris * sizeof(DevTriF);
