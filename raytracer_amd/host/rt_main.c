@@ -129,16 +129,31 @@ int main(int argc, char** argv) {
     printf("tile plan tuned in %.3f ms\n", tune_ms);
   }
   printf("Starting Render Process\n");
+  /* the frame that is timed and written is rendered by the production kernel; the ray counts printed below come
+   * from a second pass with the counting build (same image, tested), which is not part of "Render Took" */
+  rt_render_params p_timed = p;
+  p_timed.count_rays = 0;
   double t0 = now_s();
   if (multi) {
-    if ((rc = rt_hip_render_multi(&p, buf, &st)) != RT_OK) return fail("rt_hip_render_multi", rc);
+    if ((rc = rt_hip_render_multi(&p_timed, buf, &st)) != RT_OK) return fail("rt_hip_render_multi", rc);
   } else if (host_ppm) {
-    if ((rc = rt_hip_render(&p, buf, &st)) != RT_OK) return fail("rt_hip_render", rc);
+    if ((rc = rt_hip_render(&p_timed, buf, &st)) != RT_OK) return fail("rt_hip_render", rc);
   } else {
-    if ((rc = rt_hip_render_ppm(&p, (char*)buf, cap, &text_len, &st)) != RT_OK) return fail("rt_hip_render_ppm", rc);
+    if ((rc = rt_hip_render_ppm(&p_timed, (char*)buf, cap, &text_len, &st)) != RT_OK) return fail("rt_hip_render_ppm", rc);
   }
   double dt = now_s() - t0;
   printf("\nRender Took %f Seconds\n", dt);
+  if (count) {
+    uint8_t* scratch_image = malloc((size_t)W * H * 3 + 1);
+    rt_stats counted;
+    if (!scratch_image) return 1;
+    rc = multi ? rt_hip_render_multi(&p, scratch_image, &counted) : rt_hip_render(&p, scratch_image, &counted);
+    free(scratch_image);
+    if (rc != RT_OK) return fail("counting pass", rc);
+    st.rays_primary = counted.rays_primary;
+    st.rays_shadow = counted.rays_shadow;
+    st.rays_secondary = counted.rays_secondary;
+  }
   unsigned long long rays = st.rays_primary + st.rays_shadow + st.rays_secondary;
   printf("%llu rays (%llu primary, %llu shadow, %llu reflected), kernel %.3f ms, %.1f Mrays/s, %s\n", rays,
          (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,
