@@ -12,7 +12,7 @@
  *
  * Two probes are attached from outside through a macro on the libc call
  * qsort(): intersect_world() sorts exactly once per ray (RayTracer.c:1052), so
- * counting qsort calls counts rays the way the survey defines them, and the
+ * counting qsort calls counts rays (one ray = one call of intersect_world), and the
  * array handed to qsort shows the list occupancy and exact-zero t values.
  *
  * Built only where the reference is present (oracle/Makefile -> oracle/_ref/).
