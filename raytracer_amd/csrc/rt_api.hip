@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "rt_kernels.hip.inc"
