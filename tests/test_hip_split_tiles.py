@@ -4,7 +4,9 @@ holds with and without the per-tile triangle lists that camera rays run down ins
 for every tile, only for tiles with at most 8 triangles), and of the lists of possible blockers that the shadow rays
 run down.  A part of a tile split into four or more is one rectangle of the tile and has lists of its own (camera rays
 and, if short, shadow rays): with and without them, with every part given a shadow list however long, and with a
-refinement that splits nearly everything down to single pixels per wave."""
+refinement that splits nearly everything down to single pixels per wave.  From four parts on, whole waves render a
+part (every pixel held by several lanes that share its lists out): with that switched off, on from eight parts, and
+with the tree read from memory."""
 import json
 import os
 import subprocess
@@ -28,7 +30,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                         (4, 100000, 1, {"RT_HIP_PART_SHADOW_MAX": "100000", "RT_HIP_SPLIT_THRESHOLD": "0.2",
                                                                         "RT_HIP_LIST_MAX_WALK": "100000"}),
                                                         (2, 100000, 1, {"RT_HIP_SPLIT_THRESHOLD": "0.3", "RT_HIP_SPLIT_REFINE": "12",
-                                                                        "RT_HIP_LIST_LDS": "0"})])
+                                                                        "RT_HIP_LIST_LDS": "0"}),
+                                                        # whole waves on the parts of split tiles: off, from eight parts on with
+                                                        # short shadow lists, and with the tree's nodes left in memory
+                                                        (4, 100000, 1, {"RT_HIP_COOP": "0", "RT_HIP_SPLIT_THRESHOLD": "0.3"}),
+                                                        (4, 100000, 1, {"RT_HIP_COOP": "3", "RT_HIP_COOP_SHADOW": "4", "RT_HIP_SPLIT_THRESHOLD": "0.2"}),
+                                                        (4, 100000, 1, {"RT_HIP_LDS_NODES": "0", "RT_HIP_SPLIT_THRESHOLD": "0.3"})])
 def test_split_mesh_tiles_change_nothing_in_the_image(parts, tiles, min_cost, lists):
     # the switches exist in the development build of the library only (lib/librt_hip_dev.so, -DRT_DEV_SWITCHES)
     env = dict(os.environ, RT_HIP_LIB="dev", RT_HIP_SPLIT_PARTS=str(parts), RT_HIP_SPLIT_TILES=str(tiles), RT_HIP_SPLIT_MIN_COST=str(min_cost), **lists)
