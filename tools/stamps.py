@@ -9,7 +9,7 @@ import raytracer_amd as R
 scene = sys.argv[1] if len(sys.argv) > 1 else "cube"
 accel = {"auto": R._ffi.RT_ACCEL_AUTO, "brute": R._ffi.RT_ACCEL_BRUTE, "bvh": R._ffi.RT_ACCEL_BVH}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
 tr = 0.3 if scene.endswith("_refl") else 0.0
-W, H = 1920, 1080
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
 hip = R.HipRenderer(0)
 L = R._ffi.hip_lib()
 hip.upload(R.stock_scene(scene.replace("_refl", ""), W, H, tr))
