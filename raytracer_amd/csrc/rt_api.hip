@@ -87,6 +87,7 @@ struct Context {
   int part_shadow_max = 0;  /* ... and lists for their shadow rays up to this length (0: none, the default: with lists of
                                up to 48 or 96 the lighthouse frames are the same to the microsecond, and making them costs
                                3-4 ms when the tiles are planned; from 256 up the frames get slower) */
+  bool split_narrow = true; /* the refinement ends with rounds that split only the few slowest entries (refine_split) */
   double split_threshold = 0.85; /* the refinement splits the entries whose slowest wave ran longer than this share of the slowest of all */
   int split_max_lg = 6;     /* the refinement splits a tile into at most 2^this parts (6: one pixel per wave); 4K
                                lighthouse with mirrors 135 us with 4, 126 us with 5 or 6, 1080p the same with all three */
@@ -747,6 +748,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_SPLIT_RESORT")) cur->split_resort = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_WALK_SHADOW_MAX")) cur->walk_shadow_max = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_MIN_LG")) cur->part_min_lg = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_SPLIT_NARROW")) cur->split_narrow = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_COOP")) cur->coop_min_lg = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_COOP_SHADOW")) cur->coop_shadow_per_lane = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
