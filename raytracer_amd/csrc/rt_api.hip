@@ -428,7 +428,7 @@ int wide_node(const WideBuild& w, int b, int& stack_need) {
 constexpr int kMaxLdsTris = 320;      /* 320 * 64 B = 20 KiB of single-precision forms beside the 18 KiB the kernel keeps for values
                                          that wait out its loops: four workgroups still fit a CU */
 constexpr int kMaxReferenceObjects = 1 << 16; /* worlds up to this size keep a second device copy for RT_ACCEL_REFERENCE */
-constexpr size_t kMaxLdsPerWorkgroup = 80 * 1024;
+constexpr size_t kMaxLdsPerWorkgroup = 79 * 1024; /* two workgroups per CU, beside the walks' 1 KiB of static LDS */
 constexpr int kShadowBlock = 4;            /* shadow masks are worked out per block of this many tiles squared */
 constexpr int kMaxLdsShadowForms = 320;    /* ... and a list of its shadow rays of up to this many (21 KiB) */
 constexpr int kMaxLdsListForms = 384;      /* a mesh tile's workgroup keeps a list of up to this many forms in LDS (24 KiB) */
