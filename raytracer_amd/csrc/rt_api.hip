@@ -518,16 +518,16 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
         lds = nodes + stacks4;
         /* the plain walk runs three workgroups per CU if its LDS lets it (longer lists are read from memory); with
          * mirrors the registers allow two */
-        const bool many = !reflect && a.n_heavy > 4 * cur->n_cu && nodes + stacks4 <= (size_t)160 * 1024 / 3 - 4096;
+        const bool many = !reflect && a.n_heavy > 4 * cur->n_cu && nodes + stacks4 <= (size_t)160 * 1024 / 3 - 5120;
         if (many) stage = 5; /* the same kernel held to the registers of three waves per SIMD */
-        lds = fit_lists(lds, many ? (size_t)160 * 1024 / 3 : kMaxLdsPerWorkgroup);
-      } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3)) {
+        lds = fit_lists(lds, many ? (size_t)160 * 1024 / 3 - 1024 : kMaxLdsPerWorkgroup); /* 1 KiB of static LDS in every walk */
+      } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3 - 1024)) {
         /* with the nodes in global memory the kernels that need few registers run three workgroups per CU:
          * stacks that would cut that to two cost more than they save (1.31 M triangles, depth 27: +6 %); the
          * kernels with reflections run two per CU in any case (same mesh, reflective: -10 % with the stacks) */
         stage = 4;
         lds = stacks;
-        lds = fit_lists(lds, reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3);
+        lds = fit_lists(lds, reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3 - 1024);
       }
     }
   }
