@@ -81,6 +81,7 @@ struct Context {
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
   int part_min_lg = 2;      /* entries split into at least 2^this parts get lists of their own */
   int coop_min_lg = 2;      /* ... and from 2^this parts on whole waves render them (RenderArgs.coop_min_lg; 0: never) */
+  int coop_cam_per_lane = 16;    /* such a part's camera rays get a list of up to this many triangles per lane */
   int coop_shadow_per_lane = 32; /* such a part's shadow rays run down a list of up to this many possible blockers per lane
                                     that holds one of its pixels (2^lg lanes), instead of walking */
   int walk_shadow_max = 0;  /* walks: a whole tile's shadow rays run down their block's list if it has at most this many triangles */
@@ -750,6 +751,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_PART_MIN_LG")) cur->part_min_lg = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_SPLIT_NARROW")) cur->split_narrow = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_COOP")) cur->coop_min_lg = std::max(0, atoi(e));
+  if (const char* e = getenv("RT_HIP_COOP_CAM")) cur->coop_cam_per_lane = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_COOP_SHADOW")) cur->coop_shadow_per_lane = std::max(0, atoi(e));
   if (const char* e = getenv("RT_HIP_PART_LISTS")) cur->part_lists = atoi(e) != 0;
   if (const char* e = getenv("RT_HIP_PART_SHADOW_MAX")) cur->part_shadow_max = std::max(0, atoi(e));
