@@ -15,6 +15,7 @@ L = R._ffi.hip_lib()
 hip.upload(R.stock_scene(scene.replace("_refl", ""), W, H, tr))
 buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
 p = R.make_params(accel=accel)
+hip.tune(p)
 for _ in range(50):
     hip.render_device(buf.data_ptr(), p)
 torch.cuda.synchronize()
@@ -55,6 +56,16 @@ if WORDS > 6:  # the waves that end last: where their ticks went
         print(f"  wave ending at {end_us[i]:.2f} us (started {start_us[i]:.2f}, heavy {int(s[i, 5]) & 1}, tile {e & 0x3fffff} part {(e >> 22) & 63} of 2^{(e >> 28) & 7}): ticks per phase",
               [int(x) for x in s[i, 6:13]], "most per lane: camera-list confirms, shadow-list confirms, walk steps, leaf tests",
               [(tal >> (16 * k)) & 0xffff for k in range(4)])
+print(f"sum of wave durations / 2048 slots: heavy {dur_us[heavy].sum() / 2048:.2f} us, light {dur_us[~heavy].sum() / 2048:.2f} us")
+if WORDS > 6:
+    for i in np.argsort(-dur_us)[:16]:
+        e = int(entry[i]); tal = int(s[i, 13])
+        print(f"  long wave {dur_us[i]:.2f} us (started {start_us[i]:.2f}, tile {e & 0x3fffff} part {(e >> 22) & 63} of 2^{(e >> 28) & 7}): ticks per phase",
+              [int(x) for x in s[i, 6:13]], [(tal >> (16 * k)) & 0xffff for k in range(4)])
+    lgs = (entry[heavy] >> 28) & 7
+    for k in np.unique(lgs):
+        d = dur_us[heavy][lgs == k]
+        print(f"  heavy waves of entries split 2^{k}: {len(d)} waves, duration median {np.median(d):.2f}, max {d.max():.2f}, sum/2048 {d.sum() / 2048:.2f} us")
 print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
 hist, edges = np.histogram(end_us, bins=12)
 print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
