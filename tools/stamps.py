@@ -66,6 +66,21 @@ if WORDS > 6:
     for k in np.unique(lgs):
         d = dur_us[heavy][lgs == k]
         print(f"  heavy waves of entries split 2^{k}: {len(d)} waves, duration median {np.median(d):.2f}, max {d.max():.2f}, sum/2048 {d.sum() / 2048:.2f} us")
+# where the hardware put the workgroups: HW_ID = wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+hwid = s[:, 4] & 0xffffffff
+simd_key = (xcc << 20) | (((hwid >> 13) & 7) << 16) | (((hwid >> 12) & 1) << 12) | (((hwid >> 8) & 15) << 4) | ((hwid >> 4) & 3)
+cu_key = simd_key >> 4
+blk = np.nonzero(used)[0] // 4
+ends = {}
+for k, e, d in zip(simd_key[heavy], end_us[heavy], dur_us[heavy]):
+    a_ = ends.setdefault(int(k), [0, 0.0, 0.0]); a_[0] += 1; a_[1] = max(a_[1], float(e)); a_[2] += float(d)
+last = np.array([v[1] for v in ends.values()]); cnt_ = np.array([v[0] for v in ends.values()])
+print(f"SIMDs with heavy waves: {len(ends)}; heavy waves per SIMD min/median/max {cnt_.min()}/{int(np.median(cnt_))}/{cnt_.max()}; "
+      f"last heavy end per SIMD: min {last.min():.2f}, 10% {np.percentile(last, 10):.2f}, median {np.median(last):.2f}, 90% {np.percentile(last, 90):.2f}, max {last.max():.2f} us")
+if os.environ.get("RT_STAMPS_PLACEMENT"):
+    for c in np.unique(cu_key)[:6]:
+        m = cu_key == c
+        print(f"  CU {int(c):#x}: workgroups {sorted(set(int(x) for x in blk[m]))[:24]}")
 print("per XCD: waves, last end (us):", [(int(x), int((xcc == x).sum()), round(float(end_us[xcc == x].max()), 1)) for x in np.unique(xcc)])
 hist, edges = np.histogram(end_us, bins=12)
 print("ends histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
