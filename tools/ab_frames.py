@@ -1,6 +1,6 @@
 """Kernel time of a few frames with the library RT_HIP_LIB selects (A/B runs: one process per variant, same box).
 
-    RT_HIP_LIB=<tag> python tools/ab_frames.py scene[:refl[:W:H[:grid]]] ...
+    RT_HIP_LIB=<tag> python tools/ab_frames.py scene[:refl[:W:H[:grid[:accel]]]] ...      (accel: auto, brute, bvh)
 
 Each frame is tuned first, then timed over back-to-back launches with HIP events (best of three batches).
 """
@@ -16,9 +16,10 @@ for spec in sys.argv[1:]:
     refl = float(f[1]) if len(f) > 1 else 0.0
     W, H = (int(f[2]), int(f[3])) if len(f) > 3 else (1920, 1080)
     grid = int(f[4]) if len(f) > 4 else 1
+    accel = {"auto": R._ffi.RT_ACCEL_AUTO, "brute": R._ffi.RT_ACCEL_BRUTE, "bvh": R._ffi.RT_ACCEL_BVH}[f[5] if len(f) > 5 else "auto"]
     r.upload(R.stock_scene(scene, W, H, refl, refl if "spheres" in scene else 0.0))
     buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
-    p = R.make_params(spp_grid=grid)
+    p = R.make_params(spp_grid=grid, accel=accel)
     r.tune(p)
     r.render_device(buf.data_ptr(), p)
     torch.cuda.synchronize()
