@@ -76,6 +76,10 @@ struct Context {
   bool use_lds = true;
   bool lds_stack = true;
   bool lds_nodes = true;  /* a small tree's inner nodes are copied to LDS (development switch RT_HIP_LDS_NODES) */
+  int many_per_cu = 2;    /* the plain walk over a tree in LDS keeps its LDS to a third of a CU's from this many mesh workgroups per CU on
+                             (development switch RT_HIP_MANY_PER_CU).  Since the walk fits the registers of three waves per SIMD in either
+                             build, two workgroups per CU of mesh tiles are enough for the third to pay: 1080p lighthouse 28.8 -> 27.7 us,
+                             1440p 36.0 -> 31.9 us with 2 instead of 4 (with 1: 720p 22.1 -> 22.9 us; always: 300x300 18.3 -> 19.1 us) */
   bool crowded_first = true; /* mesh tiles in descending order of the triangles that project into them */
   int split_tiles = 256, split_parts = 2, split_min_cost = 16, split_quarters = 8, split_quarters_reflect = 128, split_max_per_cu = 4; /* the most crowded tiles run as 2 or 4 workgroups with a half or a quarter of the lanes each */
   bool part_lists = true;   /* parts of split tiles get lists of their own (walks) */
@@ -519,7 +523,7 @@ void launch(bool count, bool bvh, bool reflect, dim3 grid, hipStream_t s, const 
         lds = nodes + stacks4;
         /* the plain walk runs three workgroups per CU if its LDS lets it (longer lists are read from memory); with
          * mirrors the registers allow two */
-        const bool many = !reflect && a.n_heavy > 4 * cur->n_cu && nodes + stacks4 <= (size_t)160 * 1024 / 3 - 5120;
+        const bool many = !reflect && a.n_heavy > cur->many_per_cu * cur->n_cu && nodes + stacks4 <= (size_t)160 * 1024 / 3 - 5120;
         if (many) stage = 5; /* the same kernel held to the registers of three waves per SIMD */
         lds = fit_lists(lds, many ? (size_t)160 * 1024 / 3 - 1024 : kMaxLdsPerWorkgroup); /* 1 KiB of static LDS in every walk */
       } else if (stacks <= (reflect ? kMaxLdsPerWorkgroup : (size_t)160 * 1024 / 3 - 1024)) {
@@ -760,6 +764,7 @@ int create_context(int device) {
   if (const char* e = getenv("RT_HIP_XCD_TILES")) cur->xcd_tiles = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("RT_HIP_LDS_STACK")) cur->lds_stack = atoi(e) != 0; /* 0 = traversal stack in scratch */
   if (const char* e = getenv("RT_HIP_LDS_NODES")) cur->lds_nodes = atoi(e) != 0;
+  if (const char* e = getenv("RT_HIP_MANY_PER_CU")) cur->many_per_cu = atoi(e);
   if (const char* e = getenv("RT_HIP_LDS")) cur->use_lds = atoi(e) != 0; /* 0 = read primitives from global memory */
   if (const char* e = getenv("RT_HIP_LIGHT_PER_BLOCK")) {
     const int v = atoi(e);
